@@ -1,0 +1,156 @@
+"""ctypes binding of libdicttts_hip.so (include/dicttts_hip.h).  No torch types cross the boundary: device
+pointers are passed as integers (``tensor.data_ptr()``), the stream as ``torch.cuda.current_stream().cuda_stream``.
+
+There is NO CPU fallback here: if the shared library is missing, or no GPU is visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdicttts_hip.so")
+
+DTTS_F32, DTTS_I64 = 0, 1
+VOC_BF16, VOC_BF16X3 = 0, 1
+PART_ACOUSTIC, PART_VOCODER = 1, 2
+OUT_PRON_ATTN, OUT_DUR, OUT_MEL2WORD, OUT_DICT_ATTN, OUT_WORD_ENCODER_OUT, OUT_X_MASK, OUT_CONTEXT, OUT_MEL_LENS = range(1, 9)
+TIMER_VOC_CONV, TIMER_S2PA = 1, 2
+
+EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
+           "dtts_finalize_weights", "dtts_text2mel_encode", "dtts_text2mel_decode", "dtts_text2mel_fetch",
+           "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
+
+
+class DttsConfig(C.Structure):
+    """struct dtts_config (include/dicttts_hip.h); field <- reference hparams key"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "hidden_size", "num_heads", "enc_ffn_kernel_size", "enc_layers", "gloss_dim", "word_size",
+        "value_embedding_size", "n_phone", "audio_num_mel_bins", "latent_size", "fvae_enc_dec_hidden",
+        "fvae_kernel_size", "fvae_dec_n_layers", "fvae_enc_n_layers", "prior_glow_hidden", "glow_kernel_size",
+        "prior_glow_n_blocks", "prior_glow_n_layers", "dur_predictor_layers", "dur_predictor_kernel", "dur_chans",
+        "frames_multiple", "language_zh", "upsample_initial_channel", "n_upsamples")] + [
+        ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("n_resblock_kernels", C.c_int32),
+        ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
+        ("vocoder_precision", C.c_int32)]
+
+
+class DttsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the in-tree library; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DttsError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C dict_tts_amd/csrc` (there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(path)
+    vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
+    lib.dtts_default_config.argtypes = [C.POINTER(DttsConfig)]
+    lib.dtts_default_config.restype = None
+    lib.dtts_create.argtypes = [C.POINTER(DttsConfig), C.POINTER(vp)]
+    lib.dtts_destroy.argtypes = [vp]
+    lib.dtts_destroy.restype = None
+    lib.dtts_last_error.argtypes = [vp]
+    lib.dtts_last_error.restype = C.c_char_p
+    lib.dtts_load_weight.argtypes = [vp, C.c_char_p, vp, i64p, i32, i32]
+    lib.dtts_finalize_weights.argtypes = [vp, i32]
+    lib.dtts_text2mel_encode.argtypes = [vp] + [vp] * 8 + [i32] * 5 + [C.POINTER(C.c_int32), vp]
+    lib.dtts_text2mel_decode.argtypes = [vp, vp, vp, vp]
+    lib.dtts_text2mel_fetch.argtypes = [vp, i32, vp, vp]
+    lib.dtts_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.dtts_hifigan_hop.argtypes = [vp]
+    lib.dtts_timer_enable.argtypes = [vp, i32]
+    lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.dtts_timer_reset.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def default_config():
+    cfg = DttsConfig()
+    load_library().dtts_default_config(C.byref(cfg))
+    return cfg
+
+
+class Context:
+    """One dtts_handle (single owner, one per GPU / process)."""
+
+    def __init__(self, cfg=None):
+        self.lib = load_library()
+        self.cfg = cfg or default_config()
+        self.h = C.c_void_p()
+        rc = self.lib.dtts_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise DttsError(f"dtts_create failed ({rc}): {self.lib.dtts_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dtts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DttsError(f"{what} failed ({rc}): {self.lib.dtts_last_error(self.h).decode()}")
+
+    def load_state_dict(self, prefix, state):
+        """state: mapping name -> numpy array or torch tensor (fp32); names are the reference's keys"""
+        for k, v in state.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            if a.dtype != np.float32:
+                if not np.issubdtype(a.dtype, np.floating):
+                    continue  # e.g. num_batches_tracked-style integer buffers: not part of this path
+                a = a.astype(np.float32)
+            a = np.ascontiguousarray(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._chk(self.lib.dtts_load_weight(self.h, f"{prefix}.{k}".encode(), a.ctypes.data_as(C.c_void_p), shape,
+                                                a.ndim, DTTS_F32), f"dtts_load_weight({k})")
+
+    def finalize(self, parts):
+        self._chk(self.lib.dtts_finalize_weights(self.h, parts), "dtts_finalize_weights")
+
+    def hop(self):
+        return self.lib.dtts_hifigan_hop(self.h)
+
+    def text2mel_encode(self, word_tokens, keys, values, key_map, pinyin, pinyin_map, pron_modified, mel2word, B, T_w,
+                        L_k, P, stream):
+        """all tensor arguments are device pointers (ints, 0/None = NULL); returns T_mel"""
+        t_mel = C.c_int32(0)
+        m2w_ptr, T_m2w = (mel2word if mel2word else (None, 0))
+        self._chk(self.lib.dtts_text2mel_encode(self.h, word_tokens, keys, values, key_map, pinyin, pinyin_map,
+                                                pron_modified or None, m2w_ptr, T_m2w, B, T_w, L_k, P, C.byref(t_mel),
+                                                stream), "dtts_text2mel_encode")
+        return t_mel.value
+
+    def text2mel_decode(self, z_p, mel_out, stream):
+        self._chk(self.lib.dtts_text2mel_decode(self.h, z_p, mel_out, stream), "dtts_text2mel_decode")
+
+    def fetch(self, what, dst, stream):
+        self._chk(self.lib.dtts_text2mel_fetch(self.h, what, dst, stream), "dtts_text2mel_fetch")
+
+    def hifigan_forward(self, mel, lens, B, T, wav, stream):
+        self._chk(self.lib.dtts_hifigan_forward(self.h, mel, lens or None, B, T, wav, stream), "dtts_hifigan_forward")
+
+    def timer_enable(self, which):
+        self._chk(self.lib.dtts_timer_enable(self.h, which), "dtts_timer_enable")
+
+    def timer_read(self, which):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._chk(self.lib.dtts_timer_read(self.h, which, C.byref(ms), C.byref(n)), "dtts_timer_read")
+        return ms.value, n.value
+
+    def timer_reset(self):
+        self._chk(self.lib.dtts_timer_reset(self.h), "dtts_timer_reset")

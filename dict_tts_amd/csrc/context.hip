@@ -1,0 +1,1084 @@
+// libdicttts_hip.so — context, weight folding/packing, and the orchestration of the two entry points
+// (acoustic model, vocoder).  C ABI declared in include/dicttts_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dicttts_hip.h"
+#include "conv1d.h"
+#include "ops.h"
+
+using namespace dtts;
+
+namespace {
+
+struct HostTensor {
+    std::vector<float> f;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    hipError_t reserve(size_t n) {
+        off = 0;
+        if (n <= cap) return hipSuccess;
+        if (base) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return e;
+            (void)hipFree(base);
+            base = nullptr;
+            cap = 0;
+        }
+        n = n + n / 8 + (1 << 20);
+        hipError_t e = hipMalloc((void**)&base, n);
+        if (e != hipSuccess) return e;
+        cap = n;
+        return hipSuccess;
+    }
+    template <class T>
+    T* alloc(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = off = 0;
+    }
+};
+
+struct EncLayer {
+    PackedConv qkv, o, ffn1, ffn2;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+struct Encoder {
+    std::vector<EncLayer> l;
+    float *lg = nullptr, *lb = nullptr;
+};
+struct WNet {
+    PackedConv cond;
+    std::vector<PackedConv> in, rs;
+    int hidden = 0, layers = 0;
+};
+struct Flow {
+    PackedConv pre, post;
+    WNet wn;
+    int in_coff = 0, out_coff = 0;  // physical channel offsets of the logical x0 / x1 halves (flip parity)
+};
+
+struct TimerSlot {
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    double ms_done = 0;
+    int64_t launches = 0;
+};
+
+} // namespace
+
+struct dtts_ctx {
+    dtts_config cfg;
+    std::string err;
+    std::map<std::string, HostTensor> w;
+    std::vector<void*> allocs;
+    bool acoustic_ready = false, vocoder_ready = false;
+    // ---- acoustic model
+    float *word_emb = nullptr, *pinyin_emb = nullptr;
+    Encoder sem, lin;
+    PackedConv s2_q, s2_kT, s2_v, s2_o;
+    std::vector<PackedConv> dur_conv;
+    std::vector<float*> dur_g, dur_b;
+    float *dur_w = nullptr, *dur_bias = nullptr;
+    PackedConv g_pre, dec_pre, dec_out;
+    std::vector<Flow> flows;  // in execution (reversed) order
+    WNet dec_wn;
+    // ---- vocoder
+    PackedConv conv_pre, conv_post;
+    std::vector<PackedConv> ups;
+    std::vector<std::vector<PackedConv>> rb1, rb2;  // [resblock][3]
+    int hop = 1;
+    // ---- workspaces and per-call state
+    Arena a_enc, a_dec, a_voc;
+    int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
+    bool encoded = false;
+    float *weo = nullptr, *dur = nullptr, *pron_attn = nullptr, *dict_attn = nullptr, *context = nullptr, *x_mask = nullptr;
+    int64_t* m2w = nullptr;
+    int *mel_lens = nullptr, *lens = nullptr;
+    TimerSlot timers[3];
+};
+
+static std::string g_create_err;
+
+namespace {
+
+int fail(dtts_ctx* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) return fail(h, DTTS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
+    } while (0)
+
+template <class T>
+T* upload(dtts_ctx* h, const std::vector<T>& v) {
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    h->allocs.push_back(d);
+    return d;
+}
+
+uint16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf2f_host(uint16_t hbits) {
+    uint32_t u = (uint32_t)hbits << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Pack one convolution into MFMA fragment order and upload it.  getw(co, ci, tap) addresses the LOGICAL
+// weight; bias is in logical channel order.  gate_H > 0: logical C_out = 2*gate_H, packed co-tiles
+// alternate (tanh[32j..32j+32), sigmoid[H+32j..H+32j+32)).
+bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int K,
+               const std::function<float(int, int, int)>& getw, const std::vector<float>& bias, int dil, int stride,
+               int pad, int gate_H = 0, double flops_per_row = -1) {
+    L.engine = engine;
+    L.C_in = C_in;
+    L.C_out = C_out;
+    L.K = K;
+    L.dil = dil;
+    L.stride = stride;
+    L.pad = pad;
+    L.gate_H = gate_H;
+    L.CK = (C_in <= 32) ? 32 : 64;
+    L.C_in_pad = (C_in + L.CK - 1) / L.CK * L.CK;
+    L.C_out_pad = (C_out + 31) / 32 * 32;
+    L.flops_per_row = flops_per_row >= 0 ? flops_per_row : 2.0 * C_out * C_in * K;
+    const int KG = engine == ENG_F32 ? 8 : 16, E = KG / 2;
+    const int NG = L.C_in_pad / KG, NCT = L.C_out_pad / 32;
+    const size_t n = (size_t)K * L.C_in_pad * L.C_out_pad;
+    std::vector<float> wf;
+    std::vector<uint16_t> whi, wlo;
+    if (engine == ENG_F32) wf.assign(n, 0.f);
+    else {
+        whi.assign(n, 0);
+        if (engine == ENG_BF16X3) wlo.assign(n, 0);
+    }
+    for (int pco = 0; pco < L.C_out_pad; ++pco) {
+        int co = pco;
+        if (gate_H) {
+            const int tile = pco / 32, j = tile / 2, within = pco % 32;
+            co = (tile & 1) ? gate_H + j * 32 + within : j * 32 + within;
+            if (j * 32 + within >= gate_H) co = -1;
+        }
+        if (co < 0 || co >= C_out) continue;
+        const int ct = pco / 32, col = pco % 32;
+        for (int tap = 0; tap < K; ++tap)
+            for (int ci = 0; ci < C_in; ++ci) {
+                const int g = ci / KG, within = ci % KG, half = within / E, e = within % E;
+                const size_t idx = ((((size_t)tap * NG + g) * NCT + ct) * 64 + half * 32 + col) * E + e;
+                const float v = getw(co, ci, tap);
+                if (engine == ENG_F32) wf[idx] = v;
+                else {
+                    const uint16_t hi = f2bf_host(v);
+                    whi[idx] = hi;
+                    if (engine == ENG_BF16X3) wlo[idx] = f2bf_host(v - bf2f_host(hi));
+                }
+            }
+    }
+    if (engine == ENG_F32) L.w_hi = upload(h, wf);
+    else {
+        L.w_hi = upload(h, whi);
+        if (engine == ENG_BF16X3) L.w_lo = upload(h, wlo);
+    }
+    L.bias = bias.empty() ? nullptr : upload(h, bias);
+    return L.w_hi != nullptr && (bias.empty() || L.bias != nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight access
+struct Need {
+    dtts_ctx* h;
+    std::string missing;
+    const HostTensor* get(const std::string& name) {
+        auto it = h->w.find(name);
+        if (it == h->w.end()) {
+            if (missing.empty()) missing = name;
+            return nullptr;
+        }
+        return &it->second;
+    }
+};
+
+// fold weight norm if <base>.weight is absent: w = v * (g / ||v||), norm over all dims but 0
+// (torch.nn.utils.weight_norm dim=0; remove_weight_norm at tasks/tts/ps_flow.py:262-268, hifigan.py:144-151)
+const HostTensor* folded_weight(dtts_ctx* h, Need& need, const std::string& base) {
+    auto it = h->w.find(base + ".weight");
+    if (it != h->w.end()) return &it->second;
+    const HostTensor* g = need.get(base + ".weight_g");
+    const HostTensor* v = need.get(base + ".weight_v");
+    if (!g || !v) return nullptr;
+    HostTensor out;
+    out.shape = v->shape;
+    out.f.resize(v->f.size());
+    const int64_t d0 = v->shape[0], inner = v->numel() / d0;
+    for (int64_t i = 0; i < d0; ++i) {
+        double ss = 0;
+        for (int64_t j = 0; j < inner; ++j) ss += (double)v->f[i * inner + j] * v->f[i * inner + j];
+        const float nrm = (float)std::sqrt(ss);
+        const float sc = g->f[i] / nrm;
+        for (int64_t j = 0; j < inner; ++j) out.f[i * inner + j] = v->f[i * inner + j] * sc;
+    }
+    auto& slot = h->w[base + ".weight"];
+    slot = std::move(out);
+    return &slot;
+}
+
+std::vector<float> bias_of(Need& need, const std::string& base) {
+    const HostTensor* b = need.get(base + ".bias");
+    return b ? b->f : std::vector<float>();
+}
+
+// ordinary Conv1d weight [C_out][C_in][K]
+bool pack_plain(dtts_ctx* h, Need& need, PackedConv& L, int engine, const std::string& base, int dil, int stride, int pad,
+                bool with_bias = true, int gate_H = 0) {
+    const HostTensor* w = folded_weight(h, need, base);
+    if (!w) return false;
+    const int C_out = (int)w->shape[0], C_in = (int)w->shape[1], K = w->shape.size() > 2 ? (int)w->shape[2] : 1;
+    std::vector<float> bias = with_bias ? bias_of(need, base) : std::vector<float>();
+    if (with_bias && bias.empty()) return false;
+    const float* p = w->f.data();
+    return pack_conv(h, L, engine, C_out, C_in, K,
+                     [=](int co, int ci, int tap) { return p[((size_t)co * C_in + ci) * K + tap]; }, bias, dil, stride,
+                     pad, gate_H);
+}
+
+// ConvTranspose1d weight [C_in][C_out][k], stride u, padding p -> polyphase Conv1d with u*C_out channels
+// (phase-major), taps over input offsets {-1,0,+1} (or a single tap when k == u, p == 0):
+// out[u*q + r] = sum_delta sum_ci x[q + delta][ci] * w[ci][co][r + p - u*delta]
+bool pack_transposed(dtts_ctx* h, Need& need, PackedConv& L, int engine, const std::string& base, int u, int p) {
+    const HostTensor* w = folded_weight(h, need, base);
+    if (!w) return false;
+    const int C_in = (int)w->shape[0], C_out = (int)w->shape[1], k = (int)w->shape[2];
+    std::vector<float> b0 = bias_of(need, base);
+    if (b0.empty()) return false;
+    if (k > 2 * u || p >= u) {
+        fail(h, DTTS_E_INVAL, "%s: unsupported transposed conv k=%d stride=%d pad=%d", base.c_str(), k, u, p);
+        return false;
+    }
+    const bool single = (k == u && p == 0);
+    const int K = single ? 1 : 3, pad = single ? 0 : 1;
+    std::vector<float> bias((size_t)u * C_out);
+    for (int r = 0; r < u; ++r)
+        for (int co = 0; co < C_out; ++co) bias[(size_t)r * C_out + co] = b0[co];
+    const float* pw = w->f.data();
+    return pack_conv(
+        h, L, engine, u * C_out, C_in, K,
+        [=](int pco, int ci, int tap) {
+            const int r = pco / C_out, co = pco % C_out, delta = tap - pad;
+            const int j = r + p - u * delta;
+            return (j >= 0 && j < k) ? pw[((size_t)ci * C_out + co) * k + j] : 0.f;
+        },
+        bias, 1, 1, pad, 0, 2.0 * C_in * C_out * k /* per INPUT row: u outputs x k/u taps */);
+}
+
+float* upload_named(dtts_ctx* h, Need& need, const std::string& name) {
+    const HostTensor* t = need.get(name);
+    return t ? upload(h, t->f) : nullptr;
+}
+
+bool build_encoder(dtts_ctx* h, Need& need, Encoder& E, const std::string& p) {
+    const int n = h->cfg.enc_layers, C = h->cfg.hidden_size, K = h->cfg.enc_ffn_kernel_size;
+    E.l.resize(n);
+    for (int i = 0; i < n; ++i) {
+        EncLayer& l = E.l[i];
+        const std::string a = p + ".attn_layers." + std::to_string(i);
+        const HostTensor *wq = need.get(a + ".conv_q.weight"), *wk = need.get(a + ".conv_k.weight"),
+                         *wv = need.get(a + ".conv_v.weight");
+        const HostTensor *bq = need.get(a + ".conv_q.bias"), *bk = need.get(a + ".conv_k.bias"),
+                         *bv = need.get(a + ".conv_v.bias");
+        if (!wq || !wk || !wv || !bq || !bk || !bv) return false;
+        std::vector<float> bias(3 * C);
+        for (int c = 0; c < C; ++c) {
+            bias[c] = bq->f[c];
+            bias[C + c] = bk->f[c];
+            bias[2 * C + c] = bv->f[c];
+        }
+        const float *pq = wq->f.data(), *pk = wk->f.data(), *pv = wv->f.data();
+        if (!pack_conv(h, l.qkv, ENG_F32, 3 * C, C, 1,
+                       [=](int co, int ci, int) {
+                           const float* src = co < C ? pq : (co < 2 * C ? pk : pv);
+                           return src[(size_t)(co % C) * C + ci];
+                       },
+                       bias, 1, 1, 0))
+            return false;
+        if (!pack_plain(h, need, l.o, ENG_F32, a + ".conv_o", 1, 1, 0)) return false;
+        const std::string f = p + ".ffn_layers." + std::to_string(i);
+        if (!pack_plain(h, need, l.ffn1, ENG_F32, f + ".conv_1", 1, 1, K / 2)) return false;
+        if (!pack_plain(h, need, l.ffn2, ENG_F32, f + ".conv_2", 1, 1, 0)) return false;
+        l.g1 = upload_named(h, need, p + ".norm_layers_1." + std::to_string(i) + ".gamma");
+        l.b1 = upload_named(h, need, p + ".norm_layers_1." + std::to_string(i) + ".beta");
+        l.g2 = upload_named(h, need, p + ".norm_layers_2." + std::to_string(i) + ".gamma");
+        l.b2 = upload_named(h, need, p + ".norm_layers_2." + std::to_string(i) + ".beta");
+        if (!l.g1 || !l.b1 || !l.g2 || !l.b2) return false;
+    }
+    E.lg = upload_named(h, need, p + ".last_ln.gamma");
+    E.lb = upload_named(h, need, p + ".last_ln.beta");
+    return E.lg && E.lb;
+}
+
+bool build_wn(dtts_ctx* h, Need& need, WNet& W, const std::string& p, int hidden, int k, int layers) {
+    W.hidden = hidden;
+    W.layers = layers;
+    W.in.resize(layers);
+    W.rs.resize(layers);
+    for (int i = 0; i < layers; ++i) {
+        if (!pack_plain(h, need, W.in[i], ENG_F32, p + ".in_layers." + std::to_string(i), 1, 1, (k - 1) / 2, true, hidden))
+            return false;
+        if (!pack_plain(h, need, W.rs[i], ENG_F32, p + ".res_skip_layers." + std::to_string(i), 1, 1, 0)) return false;
+    }
+    return pack_plain(h, need, W.cond, ENG_F32, p + ".cond_layer", 1, 1, 0);
+}
+
+int build_acoustic(dtts_ctx* h) {
+    Need need{h, ""};
+    const dtts_config& c = h->cfg;
+    const std::string m = "model.";
+    const std::string enc = m + "dict_encoder.S2PA_module";
+    bool ok = true;
+    h->word_emb = upload_named(h, need, enc + ".word_emb.weight");
+    const std::string att = enc + ".s2pa_attention";
+    h->pinyin_emb = upload_named(h, need, att + ".pinyin_embedding.weight");
+    ok = ok && h->word_emb && h->pinyin_emb;
+    ok = ok && build_encoder(h, need, h->sem, enc + ".semantic_encoder");
+    ok = ok && build_encoder(h, need, h->lin, enc + ".linguistic_encoder");
+    // S2PA projections (no bias).  k_transform is applied TRANSPOSED to the query (see ops.h)
+    const HostTensor *wq = need.get(att + ".q_transform.weight"), *wk = need.get(att + ".k_transform.weight"),
+                     *wv = need.get(att + ".v_transform.weight"), *wo = need.get(att + ".output_transform.weight");
+    if (ok && wq && wk && wv && wo) {
+        const int H = c.hidden_size, D = c.gloss_dim;
+        const float *pq = wq->f.data(), *pk = wk->f.data(), *pv = wv->f.data(), *po = wo->f.data();
+        ok = ok && pack_conv(h, h->s2_q, ENG_F32, H, H, 1, [=](int co, int ci, int) { return pq[(size_t)co * H + ci]; }, {}, 1, 1, 0);
+        ok = ok && pack_conv(h, h->s2_kT, ENG_F32, D, H, 1, [=](int co, int ci, int) { return pk[(size_t)ci * D + co]; }, {}, 1, 1, 0);
+        ok = ok && pack_conv(h, h->s2_v, ENG_F32, H, D, 1, [=](int co, int ci, int) { return pv[(size_t)co * D + ci]; }, {}, 1, 1, 0);
+        ok = ok && pack_conv(h, h->s2_o, ENG_F32, H, H, 1, [=](int co, int ci, int) { return po[(size_t)co * H + ci]; }, {}, 1, 1, 0);
+    } else
+        ok = false;
+    // duration predictor
+    h->dur_conv.resize(c.dur_predictor_layers);
+    h->dur_g.resize(c.dur_predictor_layers);
+    h->dur_b.resize(c.dur_predictor_layers);
+    for (int i = 0; ok && i < c.dur_predictor_layers; ++i) {
+        const std::string p = m + "dur_predictor.conv." + std::to_string(i);
+        ok = ok && pack_plain(h, need, h->dur_conv[i], ENG_F32, p + ".1", 1, 1, (c.dur_predictor_kernel - 1) / 2);
+        h->dur_g[i] = upload_named(h, need, p + ".3.weight");
+        h->dur_b[i] = upload_named(h, need, p + ".3.bias");
+        ok = ok && h->dur_g[i] && h->dur_b[i];
+    }
+    h->dur_w = upload_named(h, need, m + "dur_predictor.linear.0.weight");
+    h->dur_bias = upload_named(h, need, m + "dur_predictor.linear.0.bias");
+    ok = ok && h->dur_w && h->dur_bias;
+    // FVAE
+    ok = ok && pack_plain(h, need, h->g_pre, ENG_F32, m + "fvae.g_pre_net.0", 1, 4, 2);
+    const int half = c.latent_size / 2;
+    h->flows.clear();
+    int parity = 0;
+    for (int f = c.prior_glow_n_blocks - 1; ok && f >= 0; --f) {
+        // reversed(flows): Flip, then the coupling layer (glow_modules.py:157-163).  The flip is not executed:
+        // it is tracked as a parity and folded into the channel order of pre / post.
+        parity ^= 1;
+        Flow fl;
+        const std::string p = m + "fvae.prior_flow.flows." + std::to_string(2 * f);
+        const HostTensor *wpre = need.get(p + ".pre.weight"), *wpost = need.get(p + ".post.weight");
+        std::vector<float> bpre = bias_of(need, p + ".pre"), bpost = bias_of(need, p + ".post");
+        if (!wpre || !wpost || bpre.empty() || bpost.empty()) { ok = false; break; }
+        const int Hf = c.prior_glow_hidden;
+        const float *ppre = wpre->f.data(), *ppost = wpost->f.data();
+        const bool rev = parity == 1;
+        // logical x0[c] = phys[rev ? 15 - c : c], c < half ; logical x1[c] = phys[rev ? 7 - c : 8 + c]
+        fl.in_coff = rev ? half : 0;
+        fl.out_coff = rev ? 0 : half;
+        ok = ok && pack_conv(h, fl.pre, ENG_F32, Hf, half, 1,
+                             [=](int co, int ci, int) { return ppre[(size_t)co * half + (rev ? half - 1 - ci : ci)]; }, bpre, 1, 1, 0);
+        std::vector<float> nb(half);
+        for (int q = 0; q < half; ++q) nb[q] = -bpost[rev ? half - 1 - q : q];
+        // x1 = x1 - m  ->  epilogue residual add with negated weights
+        ok = ok && pack_conv(h, fl.post, ENG_F32, half, Hf, 1,
+                             [=](int co, int ci, int) { return -ppost[(size_t)(rev ? half - 1 - co : co) * Hf + ci]; }, nb, 1, 1, 0);
+        ok = ok && build_wn(h, need, fl.wn, p + ".enc", Hf, c.glow_kernel_size, c.prior_glow_n_layers);
+        h->flows.push_back(fl);
+    }
+    if (ok && parity != 0) return fail(h, DTTS_E_INVAL, "odd number of flow blocks is not supported");
+    ok = ok && pack_transposed(h, need, h->dec_pre, ENG_F32, m + "fvae.decoder.pre_net.0", 4, 0);
+    ok = ok && build_wn(h, need, h->dec_wn, m + "fvae.decoder.wn", c.fvae_enc_dec_hidden, c.fvae_kernel_size, c.fvae_dec_n_layers);
+    ok = ok && pack_plain(h, need, h->dec_out, ENG_F32, m + "fvae.decoder.out_proj", 1, 1, 0);
+    if (!ok) {
+        if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
+        if (h->err.empty()) return fail(h, DTTS_E_NOMEM, "packing / uploading acoustic weights failed");
+        return DTTS_E_INVAL;
+    }
+    h->acoustic_ready = true;
+    return DTTS_OK;
+}
+
+int build_vocoder(dtts_ctx* h) {
+    Need need{h, ""};
+    const dtts_config& c = h->cfg;
+    const int eng = c.vocoder_precision == DTTS_VOC_BF16X3 ? ENG_BF16X3 : ENG_BF16;
+    const std::string v = "vocoder.";
+    bool ok = pack_plain(h, need, h->conv_pre, eng, v + "conv_pre", 1, 1, 3);
+    h->ups.resize(c.n_upsamples);
+    h->hop = 1;
+    for (int i = 0; ok && i < c.n_upsamples; ++i) {
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        ok = ok && pack_transposed(h, need, h->ups[i], eng, v + "ups." + std::to_string(i), u, (k - u) / 2);
+        h->hop *= u;
+    }
+    const int nk = c.n_resblock_kernels;
+    h->rb1.assign((size_t)c.n_upsamples * nk, {});
+    h->rb2.assign((size_t)c.n_upsamples * nk, {});
+    for (int i = 0; ok && i < c.n_upsamples * nk; ++i) {
+        const int j = i % nk, k = c.resblock_kernel_sizes[j];
+        h->rb1[i].resize(3);
+        h->rb2[i].resize(3);
+        for (int mth = 0; ok && mth < 3; ++mth) {
+            const int d = c.resblock_dilation_sizes[j][mth];
+            const std::string r = v + "resblocks." + std::to_string(i);
+            ok = ok && pack_plain(h, need, h->rb1[i][mth], eng, r + ".convs1." + std::to_string(mth), d, 1, (k * d - d) / 2);
+            ok = ok && pack_plain(h, need, h->rb2[i][mth], eng, r + ".convs2." + std::to_string(mth), 1, 1, (k - 1) / 2);
+        }
+    }
+    ok = ok && pack_plain(h, need, h->conv_post, eng, v + "conv_post", 1, 1, 3);
+    if (!ok) {
+        if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
+        if (h->err.empty()) return fail(h, DTTS_E_NOMEM, "packing / uploading vocoder weights failed");
+        return DTTS_E_INVAL;
+    }
+    h->vocoder_ready = true;
+    return DTTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helpers
+struct Timed {
+    dtts_ctx* h;
+    int which;
+    hipStream_t s;
+    hipEvent_t e1 = nullptr;
+    Timed(dtts_ctx* h_, int which_, hipStream_t s_) : h(h_), which(which_), s(s_) {
+        TimerSlot& t = h->timers[which];
+        if (!t.enabled) return;
+        if (t.used + 2 > t.pool.size()) {
+            for (int i = 0; i < 256; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                t.pool.push_back(e);
+            }
+        }
+        hipEvent_t e0 = t.pool[t.used];
+        e1 = t.pool[t.used + 1];
+        t.used += 2;
+        t.launches += 1;
+        (void)hipEventRecord(e0, s);
+    }
+    ~Timed() {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+};
+
+ConvParams base_params(const float* x, int ldx, int B, int T_in, int T_out, float* y, int ldy) {
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.x = x;
+    p.ldx = ldx;
+    p.x_bstride = (long long)T_in * ldx;
+    p.B = B;
+    p.T_in = T_in;
+    p.T_out = T_out;
+    p.out_div = 1.f;
+    p.out_mul = 1.f;
+    p.y_bstride_rows = T_out;
+    p.split = INT_MAX;
+    p.seg[0].y = y;
+    p.seg[0].ld = ldy;
+    return p;
+}
+void set_res(ConvParams& p, int s, const float* res, int ld) {
+    p.seg[s].res = res;
+    p.seg[s].ld_res = ld;
+}
+
+#define LAUNCH(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return fail(h, DTTS_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));             \
+    } while (0)
+
+int run_encoder(dtts_ctx* h, const Encoder& E, float* x, float* hbuf, float* qkv, float* att, float* ff, float* out,
+                const int* lens, int B, int T, hipStream_t s) {
+    const int C = h->cfg.hidden_size, F = 4 * C;
+    for (size_t i = 0; i < E.l.size(); ++i) {
+        const EncLayer& l = E.l[i];
+        LAUNCH(layernorm_launch(x, hbuf, l.g1, l.b1, 1e-4f, lens, 1, 0, B, T, C, s));
+        ConvParams p = base_params(hbuf, C, B, T, T, qkv, 3 * C);
+        LAUNCH(conv1d_launch(l.qkv, p, s));
+        LAUNCH(mha_launch(qkv, att, lens, B, T, C, h->cfg.num_heads, s));
+        p = base_params(att, C, B, T, T, x, C);
+        set_res(p, 0, x, C);
+        LAUNCH(conv1d_launch(l.o, p, s));
+        LAUNCH(layernorm_launch(x, hbuf, l.g2, l.b2, 1e-4f, lens, 0, 0, B, T, C, s));
+        p = base_params(hbuf, C, B, T, T, ff, F);
+        p.in_lens = lens;
+        p.post_act = 1;
+        LAUNCH(conv1d_launch(l.ffn1, p, s));
+        p = base_params(ff, F, B, T, T, x, C);
+        p.in_lens = lens;
+        p.out_lens = lens;
+        p.zero_masked = 1;
+        set_res(p, 0, x, C);
+        LAUNCH(conv1d_launch(l.ffn2, p, s));
+    }
+    LAUNCH(layernorm_launch(x, out, E.lg, E.lb, 1e-4f, lens, 0, 1, B, T, C, s));
+    return DTTS_OK;
+}
+
+// WN.forward with x_mask = 1 (modules/commons/wavenet.py:54-78): x is updated in place, `out` receives the skip sum
+int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float* cond, float* acts, float* out, int B,
+           int T, hipStream_t s) {
+    const int H = W.hidden;
+    ConvParams p = base_params(g, g_ld, B, T, T, cond, 2 * H * W.layers);
+    LAUNCH(conv1d_launch(W.cond, p, s));
+    for (int i = 0; i < W.layers; ++i) {
+        p = base_params(x, H, B, T, T, acts, H);
+        p.cond = cond;
+        p.ld_cond = 2 * H * W.layers;
+        p.cond_coff = i * 2 * H;
+        LAUNCH(conv1d_launch(W.in[i], p, s));
+        p = base_params(acts, H, B, T, T, x, H);
+        if (i < W.layers - 1) {
+            p.split = H;
+            set_res(p, 0, x, H);
+            p.seg[1].y = out;
+            p.seg[1].ld = H;
+            if (i > 0) set_res(p, 1, out, H);
+        } else {
+            p.seg[0].y = out;
+            if (i > 0) set_res(p, 0, out, H);
+        }
+        LAUNCH(conv1d_launch(W.rs[i], p, s));
+    }
+    return DTTS_OK;
+}
+
+} // namespace
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+extern "C" {
+
+void dtts_default_config(dtts_config* c) {
+    memset(c, 0, sizeof *c);
+    c->hidden_size = 192;
+    c->num_heads = 2;
+    c->enc_ffn_kernel_size = 5;
+    c->enc_layers = 4;
+    c->gloss_dim = 768;
+    c->word_size = 8000;
+    c->value_embedding_size = 185;
+    c->n_phone = 6;
+    c->audio_num_mel_bins = 80;
+    c->latent_size = 16;
+    c->fvae_enc_dec_hidden = 192;
+    c->fvae_kernel_size = 5;
+    c->fvae_dec_n_layers = 4;
+    c->fvae_enc_n_layers = 8;
+    c->prior_glow_hidden = 64;
+    c->glow_kernel_size = 3;
+    c->prior_glow_n_blocks = 4;
+    c->prior_glow_n_layers = 4;
+    c->dur_predictor_layers = 3;
+    c->dur_predictor_kernel = 5;
+    c->dur_chans = 128;
+    c->frames_multiple = 4;
+    c->language_zh = 1;
+    c->upsample_initial_channel = 512;
+    c->n_upsamples = 4;
+    const int ur[4] = {8, 8, 2, 2}, uk[4] = {16, 16, 4, 4}, rk[3] = {3, 7, 11};
+    for (int i = 0; i < 4; ++i) {
+        c->upsample_rates[i] = ur[i];
+        c->upsample_kernel_sizes[i] = uk[i];
+    }
+    c->n_resblock_kernels = 3;
+    for (int i = 0; i < 3; ++i) {
+        c->resblock_kernel_sizes[i] = rk[i];
+        c->resblock_dilation_sizes[i][0] = 1;
+        c->resblock_dilation_sizes[i][1] = 3;
+        c->resblock_dilation_sizes[i][2] = 5;
+    }
+    c->vocoder_precision = DTTS_VOC_BF16;
+}
+
+int dtts_create(const dtts_config* cfg, dtts_handle* out) {
+    if (!cfg || !out) return fail(nullptr, DTTS_E_INVAL, "dtts_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, DTTS_E_HIP, "dtts_create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (cfg->hidden_size % 64 || cfg->hidden_size / cfg->num_heads > 96 || cfg->gloss_dim > 768 || cfg->gloss_dim % 4 ||
+        cfg->n_upsamples > 8 || cfg->n_resblock_kernels > 4 || cfg->latent_size % 8 || cfg->prior_glow_hidden % 32 ||
+        cfg->fvae_enc_dec_hidden % 32)
+        return fail(nullptr, DTTS_E_INVAL, "dtts_create: unsupported configuration");
+    dtts_ctx* h = new dtts_ctx();
+    h->cfg = *cfg;
+    *out = h;
+    return DTTS_OK;
+}
+
+void dtts_destroy(dtts_handle h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    h->a_enc.release();
+    h->a_dec.release();
+    h->a_voc.release();
+    for (auto& t : h->timers)
+        for (auto e : t.pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+const char* dtts_last_error(dtts_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
+    if (!h || !name || !host_ptr || ndim < 0 || ndim > 8) return fail(h, DTTS_E_INVAL, "dtts_load_weight: bad argument");
+    if (dtype != DTTS_F32) return fail(h, DTTS_E_INVAL, "dtts_load_weight(%s): only fp32 tensors are accepted", name);
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    t.f.assign((const float*)host_ptr, (const float*)host_ptr + n);
+    h->w[name] = std::move(t);
+    return DTTS_OK;
+}
+
+int dtts_finalize_weights(dtts_handle h, int parts) {
+    if (!h) return DTTS_E_INVAL;
+    h->err.clear();
+    int rc = DTTS_OK;
+    if ((parts & DTTS_PART_ACOUSTIC) && !h->acoustic_ready) rc = build_acoustic(h);
+    if (rc == DTTS_OK && (parts & DTTS_PART_VOCODER) && !h->vocoder_ready) rc = build_vocoder(h);
+    if (rc == DTTS_OK) {
+        // host copies are no longer needed for finished parts
+        for (auto it = h->w.begin(); it != h->w.end();) {
+            const bool a = it->first.rfind("model.", 0) == 0 && h->acoustic_ready;
+            const bool v = it->first.rfind("vocoder.", 0) == 0 && h->vocoder_ready;
+            it = (a || v) ? h->w.erase(it) : std::next(it);
+        }
+    }
+    return rc;
+}
+
+int dtts_hifigan_hop(dtts_handle h) { return h ? h->hop : 0; }
+
+__global__ void scale_lens_kernel(const int32_t* lens, int32_t* out, int B, int T, int n_stage, const int* mult) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_stage) return;
+    const int sidx = i / B, b = i % B;
+    int l = lens ? lens[b] : T;
+    l = l < 0 ? 0 : (l > T ? T : l);
+    out[i] = l * mult[sidx];
+}
+
+int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, int B, int T, float* wav, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->vocoder_ready) return fail(h, DTTS_E_STATE, "vocoder weights not finalized");
+    if (!mel || !wav || B <= 0 || T <= 0) return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const dtts_config& c = h->cfg;
+    const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
+    // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
+    size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
+    {
+        long long rows = T;
+        int ch = c.upsample_initial_channel;
+        for (int i = 0; i < nup; ++i) {
+            rows *= c.upsample_rates[i];
+            ch /= 2;
+            max_elems = std::max<size_t>(max_elems, (size_t)B * (size_t)rows * (size_t)ch);
+        }
+    }
+    HIPCHK(h->a_voc.reserve(4 * (max_elems * sizeof(float) + 256) + (size_t)(nup + 2) * B * sizeof(int) + 8192));
+    float* bufX = h->a_voc.alloc<float>(max_elems);
+    float* bufR = h->a_voc.alloc<float>(max_elems);
+    float* bufT = h->a_voc.alloc<float>(max_elems);
+    float* bufS = h->a_voc.alloc<float>(max_elems);
+    int* lensS = h->a_voc.alloc<int>((size_t)(nup + 1) * B);
+    int* mult_d = h->a_voc.alloc<int>(nup + 1);
+    if (!bufX || !bufR || !bufT || !bufS || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    {
+        int mult[9];
+        mult[0] = 1;
+        for (int i = 0; i < nup; ++i) mult[i + 1] = mult[i] * c.upsample_rates[i];
+        HIPCHK(hipMemcpyAsync(mult_d, mult, sizeof(int) * (nup + 1), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(scale_lens_kernel, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult_d);
+    }
+    const int TV = DTTS_TIMER_VOC_CONV;
+    // conv_pre: mel [B,T,80] -> S [B,T,512]
+    int Tcur = T, ch = c.upsample_initial_channel;
+    {
+        ConvParams p = base_params(mel, c.audio_num_mel_bins, B, T, T, bufS, ch);
+        p.in_lens = lensS;
+        p.out_lens = lensS;
+        Timed tm(h, TV, s);
+        LAUNCH(conv1d_launch(h->conv_pre, p, s));
+    }
+    for (int i = 0; i < nup; ++i) {
+        const int u = c.upsample_rates[i];
+        const int* lin = lensS + (size_t)i * B;
+        const int* lout = lensS + (size_t)(i + 1) * B;
+        ch /= 2;
+        {   // x = ups[i](leaky_relu(x, 0.1)) as a polyphase convolution: [B,Tcur,2ch] -> [B,Tcur,u*ch] == [B,Tcur*u,ch]
+            ConvParams p = base_params(bufS, 2 * ch, B, Tcur, Tcur, bufX, u * ch);
+            p.in_lens = lin;
+            p.out_lens = lin;
+            p.pre_act = 1;
+            p.pre_slope = 0.1f;
+            Timed tm(h, TV, s);
+            LAUNCH(conv1d_launch(h->ups[i], p, s));
+        }
+        Tcur *= u;
+        for (int j = 0; j < nk; ++j) {
+            const auto& c1 = h->rb1[(size_t)i * nk + j];
+            const auto& c2 = h->rb2[(size_t)i * nk + j];
+            for (int mth = 0; mth < 3; ++mth) {
+                const float* xin = mth == 0 ? bufX : bufR;
+                {   // xt = c1(leaky_relu(x))
+                    ConvParams p = base_params(xin, ch, B, Tcur, Tcur, bufT, ch);
+                    p.in_lens = lout;
+                    p.out_lens = lout;
+                    p.pre_act = 1;
+                    p.pre_slope = 0.1f;
+                    Timed tm(h, TV, s);
+                    LAUNCH(conv1d_launch(c1[mth], p, s));
+                }
+                {   // x = c2(leaky_relu(xt)) + x ; the last one also folds xs (+)= x and the final / num_kernels
+                    const bool last = mth == 2;
+                    ConvParams p = base_params(bufT, ch, B, Tcur, Tcur, last ? bufS : bufR, ch);
+                    p.in_lens = lout;
+                    p.out_lens = lout;
+                    p.pre_act = 1;
+                    p.pre_slope = 0.1f;
+                    set_res(p, 0, xin, ch);
+                    if (last && j > 0) {
+                        p.seg[0].res2 = bufS;
+                        p.seg[0].ld_res2 = ch;
+                    }
+                    if (last && j == nk - 1) p.out_div = (float)nk;
+                    Timed tm(h, TV, s);
+                    LAUNCH(conv1d_launch(c2[mth], p, s));
+                }
+            }
+        }
+    }
+    {   // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, hifigan.py:138)
+        const int* lout = lensS + (size_t)nup * B;
+        ConvParams p = base_params(bufS, ch, B, Tcur, Tcur, wav, 1);
+        p.in_lens = lout;
+        p.out_lens = lout;
+        p.zero_masked = 1;
+        p.pre_act = 1;
+        p.pre_slope = 0.01f;
+        p.post_act = 2;
+        Timed tm(h, TV, s);
+        LAUNCH(conv1d_launch(h->conv_post, p, s));
+    }
+    return DTTS_OK;
+}
+
+int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values,
+                         const float* key_map, const int64_t* pinyin, const int64_t* pinyin_map,
+                         const int64_t* pron_modified, const int64_t* mel2word, int T_m2w, int B, int T_w, int L_k, int P,
+                         int32_t* T_mel_host, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->acoustic_ready) return fail(h, DTTS_E_STATE, "acoustic weights not finalized");
+    if (!word_tokens || !keys || !values || !key_map || !pinyin || !pinyin_map || !T_mel_host || B <= 0 || T_w <= 0 ||
+        L_k <= 0 || P <= 0 || L_k > 1024 || P > 64)
+        return fail(h, DTTS_E_INVAL, "dtts_text2mel_encode: bad argument (B=%d T_w=%d L_k=%d P=%d)", B, T_w, L_k, P);
+    hipStream_t s = (hipStream_t)stream;
+    const dtts_config& c = h->cfg;
+    const int C = c.hidden_size, D = c.gloss_dim, F = 4 * C;
+    const size_t rows = (size_t)B * T_w;
+    h->encoded = false;
+    HIPCHK(h->a_enc.reserve(rows * (size_t)(12 * C + 3 * C + F + 2 * D + 3 * c.dur_chans + P + 8) * sizeof(float) +
+                            (size_t)B * L_k * T_w * sizeof(float) + (size_t)B * (T_w + 8) * 4 * sizeof(int) + (64 << 10)));
+    Arena& A = h->a_enc;
+    float* x = A.alloc<float>(rows * C);
+    float* hb = A.alloc<float>(rows * C);
+    float* qkv = A.alloc<float>(rows * 3 * C);
+    float* att = A.alloc<float>(rows * C);
+    float* ff = A.alloc<float>(rows * F);
+    float* enc1 = A.alloc<float>(rows * C);
+    float* q = A.alloc<float>(rows * C);
+    float* qk = A.alloc<float>(rows * D);
+    float* wv = A.alloc<float>(rows * D);
+    float* v = A.alloc<float>(rows * C);
+    float* pron = A.alloc<float>(rows * C);
+    h->context = A.alloc<float>(rows * C);
+    h->weo = A.alloc<float>(rows * C);
+    h->dur = A.alloc<float>(rows);
+    h->pron_attn = A.alloc<float>(rows * P);
+    h->dict_attn = A.alloc<float>((size_t)B * L_k * T_w);
+    float* d0 = A.alloc<float>(rows * c.dur_chans);
+    float* d1 = A.alloc<float>(rows * c.dur_chans);
+    h->lens = A.alloc<int>(B);
+    int* ilens = A.alloc<int>(B);
+    int* starts = A.alloc<int>((size_t)B * (T_w + 1));
+    h->mel_lens = A.alloc<int>(B);
+    int* pm_max = A.alloc<int>(1);
+    if (!x || !hb || !qkv || !att || !ff || !enc1 || !q || !qk || !wv || !v || !pron || !h->context || !h->weo || !h->dur ||
+        !h->pron_attn || !h->dict_attn || !d0 || !d1 || !h->lens || !ilens || !starts || !h->mel_lens || !pm_max)
+        return fail(h, DTTS_E_NOMEM, "encoder workspace");
+    h->B = B;
+    h->T_w = T_w;
+    h->L_k = L_k;
+    h->P = P;
+    // A1: embedding * sqrt(hidden), lengths
+    LAUNCH(embed_launch(word_tokens, h->word_emb, sqrtf((float)C), x, h->lens, B, T_w, C, c.word_size, s));
+    // A2: semantic encoder
+    int rc = run_encoder(h, h->sem, x, hb, qkv, att, ff, enc1, h->lens, B, T_w, s);
+    if (rc) return rc;
+    // A3: S2PA
+    {
+        ConvParams p = base_params(enc1, C, B, T_w, T_w, q, C);
+        p.out_mul = (float)std::pow((double)D, -0.5);  // q * key_depth_per_head ** -0.5 (dict_encoder.py:45-46)
+        LAUNCH(conv1d_launch(h->s2_q, p, s));
+        p = base_params(q, C, B, T_w, T_w, qk, D);
+        LAUNCH(conv1d_launch(h->s2_kT, p, s));
+        LAUNCH(max_i64_launch(pinyin_map, (long long)rows * P, pm_max, s));
+        S2paArgs a;
+        a.qk = qk;
+        a.keys = keys;
+        a.values = values;
+        a.key_map = key_map;
+        a.pinyin = pinyin;
+        a.pinyin_map = pinyin_map;
+        a.pron_modified = pron_modified;
+        a.pinyin_emb = h->pinyin_emb;
+        a.pm_max = pm_max;
+        a.wv = wv;
+        a.dict_attn = h->dict_attn;
+        a.pron_attn = h->pron_attn;
+        a.pron = pron;
+        a.B = B;
+        a.T_w = T_w;
+        a.L_k = L_k;
+        a.P = P;
+        a.D = D;
+        a.H = C;
+        a.n_pinyin = c.value_embedding_size;
+        a.language_zh = c.language_zh;
+        {
+            Timed tm(h, DTTS_TIMER_S2PA, s);
+            LAUNCH(s2pa_launch(a, s));
+        }
+        p = base_params(wv, D, B, T_w, T_w, v, C);
+        LAUNCH(conv1d_launch(h->s2_v, p, s));
+        p = base_params(v, C, B, T_w, T_w, h->context, C);
+        p.out_lens = h->lens;
+        p.zero_masked = 1;  // context * x_mask (dict_encoder.py:140)
+        LAUNCH(conv1d_launch(h->s2_o, p, s));
+        LAUNCH(add_launch(h->context, pron, x, (long long)rows * C, s));
+    }
+    // A4: linguistic encoder; * (word_tokens > 0) is the same prefix mask
+    rc = run_encoder(h, h->lin, x, hb, qkv, att, ff, h->weo, h->lens, B, T_w, s);
+    if (rc) return rc;
+    // A5: duration predictor
+    LAUNCH(rowcount_nonzero_launch(h->weo, ilens, B, T_w, C, s));
+    {
+        const float* in = h->weo;
+        int cin = C;
+        for (int i = 0; i < c.dur_predictor_layers; ++i) {
+            ConvParams p = base_params(in, cin, B, T_w, T_w, d0, c.dur_chans);
+            p.post_act = 1;
+            LAUNCH(conv1d_launch(h->dur_conv[i], p, s));
+            LAUNCH(layernorm_launch(d0, d1, h->dur_g[i], h->dur_b[i], 1e-5f, ilens, 0, 1, B, T_w, c.dur_chans, s));
+            in = d1;  // next conv reads d1 and writes d0 again
+            cin = c.dur_chans;
+        }
+        LAUNCH(dur_head_launch(in, h->dur_w, h->dur_bias, ilens, h->dur, B, T_w, c.dur_chans, s));
+    }
+    // A6/A7: durations -> mel2word
+    int T_raw = 0;
+    if (!mel2word) {
+        LAUNCH(durations_launch(h->dur, ilens, starts, h->mel_lens, B, T_w, s));
+        std::vector<int> tot(B);
+        HIPCHK(hipMemcpyAsync(tot.data(), h->mel_lens, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));  // the one host sync of the path: T_mel sizes every later buffer
+        for (int b = 0; b < B; ++b) T_raw = std::max(T_raw, tot[b]);
+    } else {
+        if (T_m2w <= 0) return fail(h, DTTS_E_INVAL, "mel2word given with T_m2w=%d", T_m2w);
+        T_raw = T_m2w;
+    }
+    const int fm = c.frames_multiple;
+    const int T_mel = (T_raw % fm) ? T_raw + fm - T_raw % fm : T_raw;
+    const int T4 = T_mel / 4;
+    const size_t mrows = (size_t)B * T_mel, qrows = (size_t)B * T4;
+    const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
+    HIPCHK(h->a_dec.reserve(mrows * (size_t)(C + 1 + 2 + 2 * Hd * c.fvae_dec_n_layers + 3 * Hd + 8) * sizeof(float) +
+                            qrows * (size_t)(C + c.latent_size + 2 * Hf * c.prior_glow_n_layers + 3 * Hf + 8) * sizeof(float) +
+                            (64 << 10)));
+    h->m2w = h->a_dec.alloc<int64_t>(mrows);
+    h->x_mask = h->a_dec.alloc<float>(mrows);
+    if (!h->m2w || !h->x_mask) return fail(h, DTTS_E_NOMEM, "decoder workspace");
+    if (!mel2word) LAUNCH(mel2word_fill_launch(starts, h->mel_lens, ilens, h->m2w, B, T_w, T_raw, T_mel, s));
+    else LAUNCH(mel2word_copy_launch(mel2word, h->m2w, h->mel_lens, B, T_m2w, T_mel, s));
+    h->T_mel = T_mel;
+    *T_mel_host = T_mel;
+    h->encoded = true;
+    return DTTS_OK;
+}
+
+int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->encoded) return fail(h, DTTS_E_STATE, "dtts_text2mel_decode called before a successful dtts_text2mel_encode");
+    if (!z_p || !mel_out) return fail(h, DTTS_E_INVAL, "dtts_text2mel_decode: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const dtts_config& c = h->cfg;
+    const int B = h->B, T = h->T_mel, T4 = T / 4, C = c.hidden_size, Z = c.latent_size;
+    const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
+    const size_t mrows = (size_t)B * T, qrows = (size_t)B * T4;
+    Arena& A = h->a_dec;
+    // (m2w and x_mask were allocated first by encode; everything below is re-allocated after them on every call)
+    A.off = 0;
+    (void)A.alloc<int64_t>(mrows);
+    (void)A.alloc<float>(mrows);
+    float* g = A.alloc<float>(mrows * C);
+    float* gs = A.alloc<float>(qrows * C);
+    float* z = A.alloc<float>(qrows * Z);
+    float* fcond = A.alloc<float>(qrows * 2 * Hf * c.prior_glow_n_layers);
+    float* fh = A.alloc<float>(qrows * Hf);
+    float* facts = A.alloc<float>(qrows * Hf);
+    float* fout = A.alloc<float>(qrows * Hf);
+    float* dcond = A.alloc<float>(mrows * 2 * Hd * c.fvae_dec_n_layers);
+    float* dx = A.alloc<float>(mrows * Hd);
+    float* dacts = A.alloc<float>(mrows * Hd);
+    float* dout = A.alloc<float>(mrows * Hd);
+    if (!g || !gs || !z || !fcond || !fh || !facts || !fout || !dcond || !dx || !dacts || !dout)
+        return fail(h, DTTS_E_NOMEM, "decoder workspace");
+    // A7: gather-expand (x * tgt_nonpadding is implied: padded frames gather the zero row)
+    LAUNCH(expand_launch(h->weo, h->m2w, g, h->x_mask, B, h->T_w, T, C, s));
+    // A8: g_sqz = Conv1d(k=8, s=4, p=2)(g)
+    ConvParams p = base_params(g, C, B, T, T4, gs, C);
+    LAUNCH(conv1d_launch(h->g_pre, p, s));
+    LAUNCH(transpose_cf_to_cl_launch(z_p, z, B, Z, T4, s));
+    // A9: prior flow, reverse
+    for (const Flow& fl : h->flows) {
+        p = base_params(z, Z, B, T4, T4, fh, Hf);
+        p.x_coff = fl.in_coff;
+        LAUNCH(conv1d_launch(fl.pre, p, s));
+        int rc = run_wn(h, fl.wn, fh, gs, C, fcond, facts, fout, B, T4, s);
+        if (rc) return rc;
+        p = base_params(fout, Hf, B, T4, T4, z, Z);
+        p.seg[0].coff = fl.out_coff;
+        set_res(p, 0, z, Z);
+        p.seg[0].coff_res = fl.out_coff;
+        LAUNCH(conv1d_launch(fl.post, p, s));
+    }
+    // A10: decoder
+    p = base_params(z, Z, B, T4, T4, dx, 4 * Hd);  // ConvTranspose1d(k=4,s=4): [B,T4,16] -> [B,T4,4*Hd] == [B,T,Hd]
+    LAUNCH(conv1d_launch(h->dec_pre, p, s));
+    int rc = run_wn(h, h->dec_wn, dx, g, C, dcond, dacts, dout, B, T, s);
+    if (rc) return rc;
+    p = base_params(dout, Hd, B, T, T, mel_out, c.audio_num_mel_bins);
+    LAUNCH(conv1d_launch(h->dec_out, p, s));
+    return DTTS_OK;
+}
+
+int dtts_text2mel_fetch(dtts_handle h, int what, void* dst, dtts_stream stream) {
+    if (!h || !dst) return DTTS_E_INVAL;
+    if (!h->encoded) return fail(h, DTTS_E_STATE, "dtts_text2mel_fetch before encode");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)h->B * h->T_w, mrows = (size_t)h->B * h->T_mel;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+        case DTTS_OUT_PRON_ATTN: src = h->pron_attn; bytes = rows * h->P * 4; break;
+        case DTTS_OUT_DUR: src = h->dur; bytes = rows * 4; break;
+        case DTTS_OUT_MEL2WORD: src = h->m2w; bytes = mrows * 8; break;
+        case DTTS_OUT_DICT_ATTN: src = h->dict_attn; bytes = (size_t)h->B * h->L_k * h->T_w * 4; break;
+        case DTTS_OUT_WORD_ENCODER_OUT: src = h->weo; bytes = rows * h->cfg.hidden_size * 4; break;
+        case DTTS_OUT_X_MASK: src = h->x_mask; bytes = mrows * 4; break;
+        case DTTS_OUT_CONTEXT: src = h->context; bytes = rows * h->cfg.hidden_size * 4; break;
+        case DTTS_OUT_MEL_LENS: src = h->mel_lens; bytes = (size_t)h->B * 4; break;
+        default: return fail(h, DTTS_E_INVAL, "dtts_text2mel_fetch: unknown item %d", what);
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    return DTTS_OK;
+}
+
+int dtts_timer_enable(dtts_handle h, int which) {
+    if (!h || which < 1 || which > 2) return DTTS_E_INVAL;
+    h->timers[which].enabled = true;
+    return DTTS_OK;
+}
+
+static void timer_collect(TimerSlot& t) {
+    for (size_t i = 0; i + 1 < t.used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.pool[i], t.pool[i + 1]) == hipSuccess) t.ms_done += ms;
+    }
+    t.used = 0;
+}
+
+int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches) {
+    if (!h || which < 1 || which > 2) return DTTS_E_INVAL;
+    HIPCHK(hipDeviceSynchronize());
+    TimerSlot& t = h->timers[which];
+    timer_collect(t);
+    if (ms_total) *ms_total = t.ms_done;
+    if (launches) *launches = t.launches;
+    return DTTS_OK;
+}
+
+int dtts_timer_reset(dtts_handle h) {
+    if (!h) return DTTS_E_INVAL;
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& t : h->timers) {
+        t.used = 0;
+        t.ms_done = 0;
+        t.launches = 0;
+    }
+    return DTTS_OK;
+}
+
+} // extern "C"

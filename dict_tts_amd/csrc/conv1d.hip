@@ -1,0 +1,259 @@
+// Implicit-GEMM 1-D convolution on gfx950 MFMA, channels-last.  See conv1d.h for the contract.
+//
+// GEMM view: D[t][co] = sum_{tap, ci} X[t*stride + tap*dil - pad][ci] * W[co][ci][tap]
+//   A operand = activations (rows = output time), staged once per C_in chunk into LDS with the halo rows of
+//               all taps, so that every tap is a row-shifted read of the same tile;
+//   B operand = weights, pre-packed on the host in MFMA fragment order ([tap][k-group][co-tile][lane][16 B]) so
+//               that one wave-wide 16 B/lane load is 1 KiB contiguous (L2-resident, shared by all blocks).
+// Fragment maps (cdna_hip_programming.md §3): 32x32x16 bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31];
+// 32x32x2 f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; C/D: j=l&31, i=(r&3)+8*(r>>2)+4*(l>>5).
+// For fp32 each lane reads 4 consecutive channels (one ds_read_b128) and spends them on 4 successive
+// 32x32x2 MFMAs; the weight packing uses the same k permutation, so the contraction is unchanged.
+#include "conv1d.h"
+
+namespace dtts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned f2bf(float f) {  // round-to-nearest-even fp32 -> bf16 (bits)
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
+__global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
+    constexpr int KG = (ENGINE == ENG_F32) ? 8 : 16;  // channels per k-group (one 16-B fragment per lane)
+    constexpr int PITCH = CK * ES + 16;               // +16 B: conflict-free ds_read_b128 across 16 rows
+    constexpr int TT = 32 * MT * WT;
+    constexpr int CO_T = 32 * NT * WC;
+    constexpr int NKG = CK / KG;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % WT, wc = wave / WT;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * TT;
+    const int ct0 = blockIdx.y * (CO_T / 32) + wc * NT;  // first packed co-tile of this wave
+    const int NCT = p.C_out_pad >> 5;
+    const int in_len = p.in_lens ? p.in_lens[b] : p.T_in;
+    const int out_len = p.out_lens ? p.out_lens[b] : p.T_out;
+    if (t0 >= out_len && !p.zero_masked) return;
+    const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
+    const int in0 = t0 * p.stride - p.pad;
+    const int NG = p.C_in_pad / KG;
+    char* lds_lo = smem + (size_t)rows * PITCH;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const float* xb = p.x + (long long)b * p.x_bstride + p.x_coff;
+    const bool live = t0 < out_len;
+
+    if (live)
+        for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
+            // ---- stage X[in0 .. in0+rows) x [ci0, ci0+CK) into LDS (pre-activation, zero padding, conversion)
+            for (int idx = tid; idx < rows * (CK / 4); idx += 256) {
+                const int r = idx / (CK / 4), c4 = idx % (CK / 4);
+                const int t = in0 + r, ci = ci0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < in_len && ci < p.C_in) {
+                    v = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
+                    if (p.pre_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+                    }
+                }
+                if constexpr (ENGINE == ENG_F32) {
+                    *(f32x4*)(smem + r * PITCH + c4 * 16) = v;
+                } else {
+                    unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+                    uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    *(uint2*)(smem + r * PITCH + c4 * 8) = hi;
+                    if constexpr (ENGINE == ENG_BF16X3) {
+                        unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
+                        unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
+                        *(uint2*)(lds_lo + r * PITCH + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- contraction over taps and k-groups of this chunk
+            const int g0 = ci0 / KG;
+            for (int tap = 0; tap < p.K; ++tap) {
+                const uint4* wh = (const uint4*)p.w_hi + ((size_t)(tap * NG + g0) * NCT) * 64 + lane;
+                const uint4* wl = (const uint4*)p.w_lo + ((size_t)(tap * NG + g0) * NCT) * 64 + lane;
+#pragma unroll
+                for (int kg = 0; kg < NKG; ++kg) {
+                    uint4 bh[NT], bl[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int ct = ct0 + n;
+                        if (ct < NCT) {
+                            bh[n] = wh[((size_t)kg * NCT + ct) * 64];
+                            if constexpr (ENGINE == ENG_BF16X3) bl[n] = wl[((size_t)kg * NCT + ct) * 64];
+                        } else {
+                            bh[n] = make_uint4(0, 0, 0, 0);
+                            bl[n] = make_uint4(0, 0, 0, 0);
+                        }
+                    }
+                    uint4 ah[MT], al[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int i = (wt * MT + m) * 32 + (lane & 31);
+                        const int off = (i * p.stride + tap * p.dil) * PITCH + (kg * KG + (lane >> 5) * (KG / 2)) * ES;
+                        ah[m] = *(const uint4*)(smem + off);
+                        if constexpr (ENGINE == ENG_BF16X3) al[m] = *(const uint4*)(lds_lo + off);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if constexpr (ENGINE == ENG_F32) {
+                                const f32x4 a = *(const f32x4*)&ah[m];
+                                const f32x4 w = *(const f32x4*)&bh[n];
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc[m][n], 0, 0, 0);
+                            } else {
+                                const bf16x8 a = *(const bf16x8*)&ah[m];
+                                const bf16x8 w = *(const bf16x8*)&bh[n];
+                                if constexpr (ENGINE == ENG_BF16X3) {
+                                    const bf16x8 a2 = *(const bf16x8*)&al[m];
+                                    const bf16x8 w2 = *(const bf16x8*)&bl[n];
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w, acc[m][n], 0, 0, 0);
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, acc[m][n], 0, 0, 0);
+                                }
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[m][n], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+            __syncthreads();
+        }
+
+    // ---- epilogue
+    const int col = lane & 31;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (p.gate_H && (n & 1)) continue;
+            const int ct = ct0 + n;
+            if (ct >= NCT) continue;
+            int co, co_s = 0;
+            if (p.gate_H) {
+                co = (ct >> 1) * 32 + col;   // tanh channel; sigmoid channel = gate_H + co
+                co_s = p.gate_H + co;
+            } else {
+                co = ct * 32 + col;
+            }
+            if (co >= (p.gate_H ? p.gate_H : p.C_out)) continue;
+            const float bias = p.bias ? p.bias[co] : 0.f;
+            const float bias_s = (p.gate_H && p.bias) ? p.bias[co_s] : 0.f;
+            const int s = (co >= p.split) ? 1 : 0;
+            const ConvSeg& sg = p.seg[s];
+            const int cs = co - (s ? p.split : 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + (wt * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (t >= p.T_out) continue;
+                const long long row = (long long)b * p.y_bstride_rows + t;
+                float v;
+                if (t >= out_len) {
+                    if (!p.zero_masked) continue;
+                    v = 0.f;
+                } else {
+                    v = acc[m][n][r] + bias;
+                    if (p.gate_H) {
+                        float u = acc[m][n + (NT > 1 ? 1 : 0)][r] + bias_s;
+                        if (p.cond) {
+                            const float* c = p.cond + row * p.ld_cond + p.cond_coff;
+                            v += c[co];
+                            u += c[co_s];
+                        }
+                        v = tanhf(v) * (1.f / (1.f + expf(-u)));
+                    }
+                    if (sg.res) v += sg.res[row * sg.ld_res + sg.coff_res + cs];
+                    if (sg.res2) v += sg.res2[row * sg.ld_res2 + sg.coff_res2 + cs];
+                    if (p.out_div != 1.f) v = v / p.out_div;
+                    if (p.out_mul != 1.f) v = v * p.out_mul;
+                    if (p.post_act == 1) v = fmaxf(v, 0.f);
+                    else if (p.post_act == 2) v = tanhf(v);
+                }
+                sg.y[row * sg.ld + sg.coff + cs] = v;
+            }
+        }
+    }
+}
+
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
+static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
+    constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
+    constexpr int PITCH = CK * ES + 16;
+    constexpr int TT = 32 * MT * WT, CO_T = 32 * NT * WC;
+    const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
+    size_t lds = (size_t)rows * PITCH * (ENGINE == ENG_BF16X3 ? 2 : 1);
+    auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK>;
+    static size_t configured = 0;
+    if (lds > 65536 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    dim3 grid((p.T_out + TT - 1) / TT, (p.C_out_pad + CO_T - 1) / CO_T, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int ENGINE, int CK>
+static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStream_t stream) {
+    if constexpr (ENGINE == ENG_F32) {
+        if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);  // 32 t x 256 co
+        return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                      // 128 t x 64 co
+    } else {
+        if (L.C_out_pad <= 32) return launch_cfg<ENGINE, 2, 1, 4, 1, CK>(p, stream);   // 256 t x 32 co
+        if (L.C_out_pad <= 64) return launch_cfg<ENGINE, 2, 2, 4, 1, CK>(p, stream);   // 256 t x 64 co
+        if (L.C_out_pad <= 128) return launch_cfg<ENGINE, 2, 2, 2, 2, CK>(p, stream);  // 128 t x 128 co
+        return launch_cfg<ENGINE, 2, 4, 2, 2, CK>(p, stream);                           // 128 t x 256 co
+    }
+}
+
+hipError_t conv1d_launch(const PackedConv& L, ConvParams p, hipStream_t stream) {
+    p.w_hi = L.w_hi;
+    p.w_lo = L.w_lo;
+    p.bias = L.bias;
+    p.C_in = L.C_in;
+    p.C_in_pad = L.C_in_pad;
+    p.C_out = L.C_out;
+    p.C_out_pad = L.C_out_pad;
+    p.K = L.K;
+    p.dil = L.dil;
+    p.stride = L.stride;
+    p.pad = L.pad;
+    p.gate_H = L.gate_H;
+    if (p.out_div == 0.f) p.out_div = 1.f;
+    if (p.out_mul == 0.f) p.out_mul = 1.f;
+    switch (L.engine) {
+        case ENG_F32:
+            return L.CK == 32 ? launch_engine<ENG_F32, 32>(L, p, stream) : launch_engine<ENG_F32, 64>(L, p, stream);
+        case ENG_BF16:
+            return L.CK == 32 ? launch_engine<ENG_BF16, 32>(L, p, stream) : launch_engine<ENG_BF16, 64>(L, p, stream);
+        default:
+            return L.CK == 32 ? launch_engine<ENG_BF16X3, 32>(L, p, stream)
+                              : launch_engine<ENG_BF16X3, 64>(L, p, stream);
+    }
+}
+
+size_t packed_elems(const PackedConv& L) { return (size_t)L.K * L.C_in_pad * L.C_out_pad; }
+
+} // namespace dtts

@@ -1,0 +1,160 @@
+/*
+ * libdicttts_hip.so — C ABI of the MI355X (gfx950) Dict-TTS inference hot path.
+ *
+ * The reference (Zain-Jiang/Dict-TTS) is pure Python/PyTorch and has no FFI; the two plugin points this
+ * library sits behind are:
+ *   - the acoustic model  PortaSpeech_dict.forward(..., infer=True)     modules/dict_tts/model.py:36-62
+ *   - the vocoder         HifiGAN.spec2wav(mel[T,80]) -> wav[T*256]      vocoders/hifigan.py:54-62
+ * The Python shims in dict_tts_amd/ (model.py, vocoder.py) keep those signatures and call the entry points
+ * below through ctypes.  No torch types cross this boundary: plain pointers, sizes and a hipStream_t.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DTTS_E_* code; the message is dtts_last_error().
+ *   - "dev" pointers are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()), contiguous,
+ *     row-major in the reference's layouts.  "host" pointers are ordinary host memory.
+ *   - a handle is single-owner and not thread-safe; all work is enqueued on the caller's stream.  The only
+ *     host synchronisation on the path is the T_mel scalar read in dtts_text2mel_encode().
+ */
+#ifndef DICTTTS_HIP_H
+#define DICTTTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dtts_ctx* dtts_handle;
+typedef void* dtts_stream; /* hipStream_t */
+
+#define DTTS_OK 0
+#define DTTS_E_INVAL (-22)   /* bad argument / shape                       */
+#define DTTS_E_NOMEM (-12)   /* device allocation failed                   */
+#define DTTS_E_NOENT (-2)    /* a required weight tensor was never loaded  */
+#define DTTS_E_STATE (-1)    /* call order violated (e.g. decode before encode) */
+#define DTTS_E_HIP (-5)      /* a HIP runtime call failed                  */
+
+#define DTTS_F32 0
+#define DTTS_I64 1
+
+/* vocoder arithmetic: bf16 MFMA operands with fp32 accumulation, or bf16x3 split operands (fp32-class) */
+#define DTTS_VOC_BF16 0
+#define DTTS_VOC_BF16X3 1
+
+/* Model hyper-parameters.  Field <- reference hparams key (resolved values, SURVEY.md §5 "Config / flags"). */
+typedef struct dtts_config {
+    int32_t hidden_size;          /* hidden_size 192                         egs/egs_bases/tts/ps_flow.yaml:10 */
+    int32_t num_heads;            /* num_heads 2                             egs/egs_bases/tts/base.yaml:70    */
+    int32_t enc_ffn_kernel_size;  /* enc_ffn_kernel_size 5                   ps_flow.yaml:11                   */
+    int32_t enc_layers;           /* 4, hard-coded at modules/dict_tts/layers/dict_encoder.py:104-128         */
+    int32_t gloss_dim;            /* 768: key/value size of S2PAAttention    dict_encoder.py:18                */
+    int32_t word_size;            /* word_size 8000                                                          */
+    int32_t value_embedding_size; /* value_embedding_size 185                                                */
+    int32_t n_phone;              /* rows of the unused phoneme embedding (len(phone_set)+3)                  */
+    int32_t audio_num_mel_bins;   /* 80                                      base.yaml:50                      */
+    int32_t latent_size;          /* 16                                      ps_flow.yaml:25                   */
+    int32_t fvae_enc_dec_hidden;  /* 192                                                                      */
+    int32_t fvae_kernel_size;     /* 5                                                                        */
+    int32_t fvae_dec_n_layers;    /* 4                                                                        */
+    int32_t fvae_enc_n_layers;    /* 8 (posterior encoder: loaded, unused at inference)                       */
+    int32_t prior_glow_hidden;    /* 64                                      ps_flow.yaml:32                   */
+    int32_t glow_kernel_size;     /* 3                                                                        */
+    int32_t prior_glow_n_blocks;  /* 4                                                                        */
+    int32_t prior_glow_n_layers;  /* 4, hard-coded at modules/dict_tts/fvae_semantics.py:78-79                */
+    int32_t dur_predictor_layers; /* 3                                       ps_flow.yaml:17-22                */
+    int32_t dur_predictor_kernel; /* 5                                                                        */
+    int32_t dur_chans;            /* 128, hard-coded at modules/portaspeech/model.py:164-169                  */
+    int32_t frames_multiple;      /* 4                                       ps_flow.yaml:61                   */
+    int32_t language_zh;          /* language == 'zh' -> add_pron_rule       layers/utils.py:109-115           */
+    /* HifiGAN generator                                                    egs/egs_bases/tts/vocoder/hifigan.yaml:3-10 */
+    int32_t upsample_initial_channel; /* 512 */
+    int32_t n_upsamples;              /* 4   */
+    int32_t upsample_rates[8];        /* 8,8,2,2   */
+    int32_t upsample_kernel_sizes[8]; /* 16,16,4,4 */
+    int32_t n_resblock_kernels;       /* 3   */
+    int32_t resblock_kernel_sizes[4]; /* 3,7,11 */
+    int32_t resblock_dilation_sizes[4][3]; /* (1,3,5) x3 */
+    int32_t vocoder_precision;        /* DTTS_VOC_BF16 | DTTS_VOC_BF16X3 */
+} dtts_config;
+
+/* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
+void dtts_default_config(dtts_config* cfg);
+
+/* Create / destroy a context on the current HIP device. */
+int dtts_create(const dtts_config* cfg, dtts_handle* out);
+void dtts_destroy(dtts_handle h);
+const char* dtts_last_error(dtts_handle h); /* h may be NULL: message of the last failed dtts_create */
+
+/*
+ * Weight loading — replaces torch's load_state_dict for the two children the path uses:
+ *   state_dict['model']      (utils/trainer.py:348-376, keys as in SURVEY.md §8a) -> names "model.<key>"
+ *   state_dict['model_gen']  (vocoders/hifigan.py:16-32)                           -> names "vocoder.<key>"
+ * One call per tensor, fp32 host data, the library copies it (caller keeps ownership).  Weight-norm pairs
+ * arrive as <name>.weight_g / <name>.weight_v and are folded in dtts_finalize_weights (w = g*v/||v||, what
+ * remove_weight_norm does at tasks/tts/ps_flow.py:262-268 and modules/hifigan/hifigan.py:144-151).
+ * Unknown names (fvae.encoder.*, attn.*, enc_pos_proj.* ... — loaded but unused at inference) are accepted and ignored.
+ */
+int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+
+#define DTTS_PART_ACOUSTIC 1
+#define DTTS_PART_VOCODER 2
+/* Fold, repack into MFMA fragment order and upload.  Fails with DTTS_E_NOENT naming the first missing tensor. */
+int dtts_finalize_weights(dtts_handle h, int parts);
+
+/*
+ * Acoustic model, phase 1 — replaces run_text_encoder (modules/dict_tts/model.py:84-110): S2PA dictionary
+ * encoder, duration predictor, length regulator.  Inputs are the tensors of DictTTSDataset.collater
+ * (tasks/tts/dataset_utils.py:264-302):
+ *   word_tokens [B,T_w] i64 · keys, values [B,T_w,L_k,gloss_dim] f32 · key_map [B,T_w,L_k] f32 ·
+ *   pinyin, pinyin_map [B,T_w,P] i64 · pron_modified [B,T_w] i64 (may be NULL = zeros) ·
+ *   mel2word [B,T_m2w] i64 or NULL (teacher-forced durations, model.py:77).
+ * On return *T_mel_host is the frame count padded to frames_multiple (model.py:98-100).  This call
+ * synchronises the stream once to read that scalar when mel2word is NULL.
+ */
+int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+                         const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
+                         const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k,
+                         int P, int32_t* T_mel_host, dtts_stream stream);
+
+/*
+ * Acoustic model, phase 2 — replaces the gather-expand and run_decoder (model.py:105-121,
+ * fvae_semantics.py:109-115): z_p [B,latent,T_mel/4] f32 is the prior sample (the reference draws it from the
+ * CPU RNG; here it is an explicit input).  mel_out [B,T_mel,80] f32.
+ */
+int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev, dtts_stream stream);
+
+/* Copy an intermediate of the last encode/decode into a caller buffer (device to device, on the stream). */
+#define DTTS_OUT_PRON_ATTN 1        /* [B,T_w,P] f32      ret['pron_attn']          */
+#define DTTS_OUT_DUR 2              /* [B,T_w] f32        ret['dur'] (log domain)   */
+#define DTTS_OUT_MEL2WORD 3         /* [B,T_mel] i64                                */
+#define DTTS_OUT_DICT_ATTN 4        /* [B,1,L_k,T_w] f32  ret['dict_attn']          */
+#define DTTS_OUT_WORD_ENCODER_OUT 5 /* [B,T_w,hidden] f32                           */
+#define DTTS_OUT_X_MASK 6           /* [B,T_mel,1] f32    ret['x_mask']             */
+#define DTTS_OUT_CONTEXT 7          /* [B,T_w,hidden] f32 S2PA context              */
+#define DTTS_OUT_MEL_LENS 8         /* [B] i32 valid (unpadded) frames per utterance */
+int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stream);
+
+/*
+ * Vocoder — replaces HifiGanGenerator.forward as used by HifiGAN.spec2wav (vocoders/hifigan.py:54-62), for a
+ * batch: mel [B,T,80] f32 (the layout of ret['mel_out'] and of spec2wav's argument), lens [B] i32 valid
+ * frames per utterance (NULL = T for all).  wav [B, T*hop] f32; utterance b is exactly what the reference
+ * produces for mel[b,:lens[b]] alone, samples past lens[b]*hop are zero.
+ */
+int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* lens_dev, int B, int T, float* wav_dev,
+                         dtts_stream stream);
+int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
+
+/*
+ * Instrumentation used by bench.py: accumulated device time (hipEvent pairs recorded on the caller's stream
+ * around every launch of one kernel family) since the last reset.
+ */
+#define DTTS_TIMER_VOC_CONV 1   /* the vocoder's MFMA convolution kernel (dominant kernel) */
+#define DTTS_TIMER_S2PA 2       /* the S2PA dictionary-attention kernel                    */
+int dtts_timer_enable(dtts_handle h, int which);
+int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches); /* synchronises */
+int dtts_timer_reset(dtts_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
