@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the Dict-TTS inference hot path on MI355X (BASELINE.json: mel-frames/sec + audio-samples/sec
+(RTF) per GPU, Biaobei batch=60).
+
+One "step" = one pass of the whole hot path over one batch of 60 synthetic Biaobei utterances per GPU:
+    S2PA dictionary encoder -> duration predictor -> length regulator (incl. the one T_mel host sync)
+    -> prior flow + FVAE decoder -> HifiGAN (bf16 MFMA)            text ids + gloss embeddings in HBM -> waveform in HBM
+Inputs are resident in HBM before the timed region (the PCIe-inclusive figure is discussed in DESIGN.md).
+Data: synthetic (counter-based weights / gloss embeddings, real Biaobei sentence + dictionary structure); durations
+are PREDICTED by the duration predictor (its output bias is set so that the mean is ~22 frames per character).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Weak scaling: every rank processes its own batch of 60 (utterances r*60.. of the
+200-sentence test set, wrapping around); with N > 1 the mels are all-gathered over RCCL (overlapped with the vocoder).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME_VOCODER = 614_105_088   # 2*MAC of HifiGanGenerator per mel frame
+PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+DUR_BIAS = 3.09                        # exp(softplus(3.09)) - 1 ~= 22 frames per word
+
+
+def cpu_baseline(torch, np, synth, n_utt=6, max_seconds=40.0):
+    """the CPU oracle (our restatement of the reference, oracle/*.py) timed on the host cores: reference-faithful
+    protocol, B=1 per utterance, model forward + one spec2wav per utterance (tasks/tts/dict_tts.py:179-255)"""
+    from oracle import dict_tts_ref as ref
+    from oracle import hifigan_ref as href
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd_np = synth.dict_tts_state_dict(1234)
+    sd_np["dur_predictor.linear.0.bias"] = np.array([DUR_BIAS], np.float32)
+    sd = href.fold_weight_norm({k: T(v) for k, v in sd_np.items()})
+    hsd = href.fold_weight_norm({k: T(v) for k, v in synth.hifigan_state_dict(1234).items()})
+    cfg = synth.hifigan_config()
+    st = synth.biaobei_struct()
+    frames, t_total, done = 0, 0.0, 0
+    for i in range(n_utt + 1):  # first one is the warm-up
+        b = {k: T(v) for k, v in synth.make_batch([st["sentences"][i % 200]], 1234).items()}
+        t0 = time.perf_counter()
+        r = ref.forward_infer(sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                              b["pron_modified"], z_p=lambda B, T4: torch.randn(B, 16, T4))
+        wav = href.spec2wav(hsd, cfg, r["mel_out"][0].numpy())
+        dt = time.perf_counter() - t0
+        assert wav.numel() == r["mel_out"].shape[1] * 256
+        if i == 0:
+            continue
+        frames += int(r["mel_out"].shape[1])
+        t_total += dt
+        done += 1
+        if t_total > max_seconds:
+            break
+    return {"value": frames / t_total, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} Biaobei utterances at B=1 (text->mel->wav, {frames} frames, {t_total:.1f} s), torch CPU fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=60)
+    ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of mels when --gpus > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from dict_tts_amd import abi, model, synth, vocoder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    # ---- weights (random-init of the real architecture) and the acoustic model / vocoder behind the reference APIs
+    sd_np = synth.dict_tts_state_dict(1234)
+    sd_np["dur_predictor.linear.0.bias"] = np.array([DUR_BIAS], np.float32)
+    m = model.PortaSpeech_dict(hparams={})
+    m.load_state_dict({k: T(v) for k, v in sd_np.items()})
+    prec = abi.VOC_BF16 if args.precision == "bf16" else abi.VOC_BF16X3
+    voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()},
+                          config=synth.hifigan_config(), precision=prec)
+    voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
+    # ---- this rank's batch, resident in HBM
+    st = synth.biaobei_struct()
+    sent = [st["sentences"][(rank * args.batch + i) % len(st["sentences"])] for i in range(args.batch)]
+    batch = {k: T(v).to(dev) for k, v in synth.make_batch(sent, 1234).items()}
+    B, T_w = batch["word_tokens"].shape
+    L_k = batch["keys"].shape[2]
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    z_all = torch.randn(B, 16, 4096, generator=gen).to(dev)  # prior noise, sliced to T_mel/4 each step
+    CAP = 1548                                                # max_frames (egs/egs_bases/tts/base.yaml:45)
+    gather_on = world > 1 and not args.no_gather
+    if gather_on:
+        mel_pad = torch.zeros(B, CAP, 80, device=dev)
+        mel_all = torch.empty(world * B, CAP, 80, device=dev)
+        comm_stream = torch.cuda.Stream(device=dev)
+
+    def run_step():
+        # encode (one host sync: T_mel) -> decode -> vocoder; z_p sliced from the resident noise
+        stream = torch.cuda.current_stream().cuda_stream
+        ptr = lambda t: t.data_ptr()
+        T_mel = m.ctx.text2mel_encode(ptr(batch["word_tokens"]), ptr(batch["keys"]), ptr(batch["values"]),
+                                      ptr(batch["key_map"]), ptr(batch["pinyin"]), ptr(batch["pinyin_map"]),
+                                      ptr(batch["pron_modified"]), None, B, T_w, L_k, batch["pinyin"].shape[2], stream)
+        z = z_all[:, :, : T_mel // 4].contiguous()
+        mel = torch.empty(B, T_mel, 80, device=dev)
+        m.ctx.text2mel_decode(z.data_ptr(), mel.data_ptr(), stream)
+        lens = torch.empty(B, dtype=torch.int32, device=dev)
+        m.ctx.fetch(abi.OUT_MEL_LENS, lens.data_ptr(), stream)
+        work = None
+        if gather_on:
+            mel_pad[:, :T_mel] = mel[:, :CAP]
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                work = dist.all_gather_into_tensor(mel_all, mel_pad, async_op=True)
+        wav = voc.forward_batch(mel, lens)
+        if work is not None:
+            work.wait()
+        return lens, wav, T_mel
+
+    for _ in range(args.warmup):
+        lens, wav, T_mel = run_step()
+    torch.cuda.synchronize()
+    voc.ctx.timer_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames_rank = 0
+    lens_acc = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(args.steps):
+        lens, wav, T_mel = run_step()
+        lens_acc += lens.sum()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    frames_rank = int(lens_acc.item())
+    conv_ms, conv_launches = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        f = torch.tensor([frames_rank], device=dev, dtype=torch.int64)
+        dist.all_reduce(f)
+        frames_total = int(f.item())
+    else:
+        frames_total = frames_rank
+    assert torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+
+    if rank == 0:
+        value = frames_total / elapsed
+        samples = value * voc.hop
+        achieved = FLOP_PER_FRAME_VOCODER * frames_rank / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "mel-frames/sec, end-to-end text->mel->wav (audio-samples/sec = 256x; RTF reported alongside)",
+            "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "bf16x3",
+            "data": "synthetic (random-init weights of the real architecture, Biaobei sentence/dictionary structure)",
+            "config": {"workload": "BASELINE configs[1]: Biaobei batch=60 per GPU, full Dict-TTS encoder + FVAE decoder + HifiGAN, "
+                                   "predicted durations (~22 frames/char)", "utterances_per_gpu": B, "T_w": T_w, "L_k": L_k,
+                       "T_mel_padded": T_mel, "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
+                       "parallelism": f"dp{world}" + ("+allgather(mel)" if gather_on else ""),
+                       "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision},
+            "audio_samples_per_sec": samples, "rtf": 22050.0 / samples,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "dtts::conv1d_cl_kernel<bf16> (all HifiGAN layers)", "launches": conv_launches,
+                         "avg_launch_ms": conv_ms / max(conv_launches, 1), "kernel_ms_per_step": conv_ms / max(args.steps, 1),
+                         "algorithmic_flop_per_mel_frame": FLOP_PER_FRAME_VOCODER},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, np, synth)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
