@@ -78,6 +78,7 @@ def main():
     import numpy as np
     import torch
     from dict_tts_amd import abi, model, synth, vocoder
+    from dict_tts_amd.shard import shard_indices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
