@@ -16,6 +16,7 @@
 #include "../../include/dicttts_hip.h"
 #include "conv1d.h"
 #include "ops.h"
+#include "vconv.h"
 
 using namespace dtts;
 
@@ -223,7 +224,11 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
         L.w_hi = upload(h, whi);
         if (engine == ENG_BF16X3) L.w_lo = upload(h, wlo);
     }
-    L.bias = bias.empty() ? nullptr : upload(h, bias);
+    if (!bias.empty()) {
+        std::vector<float> bp(bias);
+        bp.resize(std::max<size_t>(bias.size(), (size_t)L.C_out_pad), 0.f);  // zero padded: 16 B loads in vconv's epilogue
+        L.bias = upload(h, bp);
+    }
     return L.w_hi != nullptr && (bias.empty() || L.bias != nullptr);
 }
 
@@ -604,6 +609,162 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
 
 } // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------
+// HifiGAN, bf16 mode: vconv kernels.  Every activation exists twice: the fp32 residual stream and the bf16
+// leaky_relu copy the next convolution consumes (written by the producer's epilogue).
+namespace {
+
+__global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int T, int n_stage, const int* mult) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_stage) return;
+    const int sidx = i / B, b = i % B;
+    int l = lens ? lens[b] : T;
+    l = l < 0 ? 0 : (l > T ? T : l);
+    out[i] = l * mult[sidx];
+}
+
+VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* lens, int B, int T) {
+    VConvParams p;
+    memset(&p, 0, sizeof p);
+    p.x = x;
+    p.ldx = L.C_in_pad;
+    p.w = (const uint4*)L.w_hi;
+    p.bias = L.bias;
+    p.lens = lens;
+    p.B = B;
+    p.T = T;
+    p.C_in_pad = L.C_in_pad;
+    p.C_out = L.C_out;
+    p.C_out_pad = L.C_out_pad;
+    p.K = L.K;
+    p.dil = L.dil;
+    p.pad = L.pad;
+    p.slope = 1.f;
+    p.div = 1.f;
+    return p;
+}
+
+int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int B, int T, float* wav, hipStream_t s) {
+    const dtts_config& c = h->cfg;
+    const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
+    typedef unsigned short bf;
+    size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
+    {
+        size_t rows = T;
+        int ch = c.upsample_initial_channel;
+        for (int i = 0; i < nup; ++i) {
+            rows *= c.upsample_rates[i];
+            ch /= 2;
+            max_elems = std::max<size_t>(max_elems, (size_t)B * rows * ch);
+        }
+    }
+    const int melC = h->conv_pre.C_in_pad;
+    HIPCHK(h->a_voc.reserve(max_elems * (3 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
+                            (size_t)(nup + 2) * B * sizeof(int) + (64 << 10)));
+    Arena& A = h->a_voc;
+    float* Xf = A.alloc<float>(max_elems);
+    float* Rf = A.alloc<float>(max_elems);
+    float* Sf = A.alloc<float>(max_elems);
+    bf* Xa = A.alloc<bf>(max_elems);
+    bf* Ra = A.alloc<bf>(max_elems);
+    bf* Ta = A.alloc<bf>(max_elems);
+    bf* Sa = A.alloc<bf>(max_elems);
+    bf* melb = A.alloc<bf>((size_t)B * T * melC);
+    int* lensS = A.alloc<int>((size_t)(nup + 1) * B);
+    int* mult_d = A.alloc<int>(nup + 1);
+    if (!Xf || !Rf || !Sf || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    {
+        int mult[9];
+        mult[0] = 1;
+        for (int i = 0; i < nup; ++i) mult[i + 1] = mult[i] * c.upsample_rates[i];
+        HIPCHK(hipMemcpyAsync(mult_d, mult, sizeof(int) * (nup + 1), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(scale_lens_kernel2, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult_d);
+    }
+    HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
+    const int TV = DTTS_TIMER_VOC_CONV;
+    LAUNCH(f32_to_bf16_pad_launch(mel, melb, (long long)B * T, c.audio_num_mel_bins, melC, s));
+    int Tcur = T, ch = c.upsample_initial_channel;
+    {   // conv_pre: only its leaky_relu(0.1) bf16 copy is consumed (by ups[0])
+        VConvParams p = vparams(h->conv_pre, melb, lensS, B, T);
+        p.ya = Sa;
+        p.ldya = ch;
+        p.slope = 0.1f;
+        Timed tm(h, TV, s);
+        LAUNCH(vconv_launch(p, s));
+    }
+    for (int i = 0; i < nup; ++i) {
+        const int u = c.upsample_rates[i];
+        const int* lin = lensS + (size_t)i * B;
+        const int* lout = lensS + (size_t)(i + 1) * B;
+        ch /= 2;
+        {   // ups[i] (polyphase): Sa [B,Tcur,2ch] -> Xf / Xa [B,Tcur,u*ch] == [B,Tcur*u,ch]
+            VConvParams p = vparams(h->ups[i], Sa, lin, B, Tcur);
+            p.yf = Xf;
+            p.ldyf = u * ch;
+            p.ya = Xa;
+            p.ldya = u * ch;
+            p.slope = 0.1f;
+            Timed tm(h, TV, s);
+            LAUNCH(vconv_launch(p, s));
+        }
+        Tcur *= u;
+        const bool last_stage = i == nup - 1;
+        for (int j = 0; j < nk; ++j) {
+            const auto& c1 = h->rb1[(size_t)i * nk + j];
+            const auto& c2 = h->rb2[(size_t)i * nk + j];
+            for (int mth = 0; mth < 3; ++mth) {
+                {   // xt = c1(leaky_relu(x)); only leaky_relu(xt) in bf16 is ever consumed
+                    VConvParams p = vparams(c1[mth], mth == 0 ? Xa : Ra, lout, B, Tcur);
+                    p.ya = Ta;
+                    p.ldya = ch;
+                    p.slope = 0.1f;
+                    Timed tm(h, TV, s);
+                    LAUNCH(vconv_launch(p, s));
+                }
+                {   // x = c2(leaky_relu(xt)) + x
+                    VConvParams p = vparams(c2[mth], Ta, lout, B, Tcur);
+                    p.res = mth == 0 ? Xf : Rf;
+                    p.ldres = ch;
+                    if (mth < 2) {
+                        p.yf = Rf;
+                        p.ldyf = ch;
+                        p.ya = Ra;
+                        p.ldya = ch;
+                        p.slope = 0.1f;
+                    } else {   // xs (+)= x ; the last resblock also applies / num_kernels and emits the next stage's input
+                        p.yf = Sf;
+                        p.ldyf = ch;
+                        if (j > 0) {
+                            p.res2 = Sf;
+                            p.ldres2 = ch;
+                        }
+                        if (j == nk - 1) {
+                            p.div = (float)nk;
+                            p.ya = Sa;
+                            p.ldya = ch;
+                            p.slope = last_stage ? 0.01f : 0.1f;  // F.leaky_relu default before conv_post (hifigan.py:138)
+                        }
+                    }
+                    Timed tm(h, TV, s);
+                    LAUNCH(vconv_launch(p, s));
+                }
+            }
+        }
+    }
+    {   // wav = tanh(conv_post(leaky_relu(x, 0.01)))
+        VConvParams p = vparams(h->conv_post, Sa, lensS + (size_t)nup * B, B, Tcur);
+        p.yf = wav;
+        p.ldyf = 1;
+        p.post_tanh = 1;
+        Timed tm(h, TV, s);
+        LAUNCH(vconv_launch(p, s));
+    }
+    return DTTS_OK;
+}
+
+} // namespace
+
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
@@ -726,6 +887,7 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     hipStream_t s = (hipStream_t)stream;
     const dtts_config& c = h->cfg;
     const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
+    if (c.vocoder_precision == DTTS_VOC_BF16) return hifigan_forward_bf16(h, mel, lens, B, T, wav, s);
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
     {

@@ -1,0 +1,31 @@
+// HifiGAN bf16 convolution kernel: see vconv.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dtts {
+
+struct VConvParams {
+    const unsigned short* x;  // bf16 [B][T][ldx], already activated; ldx = C_in_pad (multiple of 8)
+    int ldx;
+    const uint4* w;           // packed bf16 weights (context.hip:pack_conv)
+    const float* bias;        // [C_out_pad] (zero padded) or null
+    const int* lens;          // [B] valid rows (stride-1 convs: input rows == output rows); null -> T
+    int B, T, C_in_pad, C_out, C_out_pad, K, dil, pad;
+    float* yf;                // fp32 result [B][T][ldyf] or null
+    int ldyf;
+    unsigned short* ya;       // bf16 leaky_relu(result, slope) [B][T][ldya] or null (slope 1 = identity)
+    int ldya;
+    float slope;
+    const float* res;         // fp32 residual(s), same row indexing
+    int ldres;
+    const float* res2;
+    int ldres2;
+    float div;                // 1 or num_kernels (true division)
+    int post_tanh;
+};
+
+hipError_t vconv_launch(const VConvParams& p, hipStream_t stream);
+hipError_t f32_to_bf16_pad_launch(const float* x, unsigned short* y, long long rows, int C, int C_pad, hipStream_t s);
+
+} // namespace dtts

@@ -1,0 +1,215 @@
+// HifiGAN convolution kernel (bf16 MFMA, fp32 accumulate), the dominant kernel of the path.
+//
+// Differences from the generic conv1d_cl_kernel (conv1d.hip):
+//   * the input is the bf16, already-activated tensor the PRODUCING kernel wrote next to its fp32 result
+//     (leaky_relu and the bf16 rounding happen exactly once, in the producer's epilogue) - staging is a pure
+//     16 B/lane copy of half the bytes;
+//   * weights are the A operand, activations the B operand: D[co][t], so a lane owns 4 consecutive output
+//     channels of one time row -> 16 B residual loads / fp32 stores and 8 B bf16 stores instead of 4 B ones;
+//   * waves are arranged over OUTPUT CHANNELS first (each weight fragment is fetched by exactly one wave of the
+//     block), every wave owns MT=4 row tiles, and weight fragments are prefetched through a register ring PF
+//     k-steps ahead, so L2 latency is covered by MFMA work instead of being exposed per k-step;
+//   * dual-output epilogue: fp32 residual stream + bf16 leaky_relu copy for the next convolution.
+// Same packed-weight format as conv1d.hip (context.hip:pack_conv), same contraction, same rounding points.
+#include "vconv.h"
+
+namespace dtts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned vf2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <int MT, int NT, int WT, int WC, int CK>
+__global__ __launch_bounds__(256) void vconv_kernel(const VConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PITCH = CK * 2 + 16;
+    constexpr int TT = 32 * MT * WT;
+    constexpr int CO_T = 32 * NT * WC;
+    constexpr int NKG = CK / 16;
+    constexpr int R = NKG < 4 ? NKG : 4;  // weight-fragment ring slots
+    constexpr int PF = R - 1;             // prefetch distance in k-steps
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % WT, wc = wave / WT;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * TT;
+    const int len = p.lens ? p.lens[b] : p.T;
+    if (t0 >= len) return;
+    const int ct0 = blockIdx.y * (CO_T / 32) + wc * NT;
+    const int NCT = p.C_out_pad >> 5;
+    const int NG = p.C_in_pad >> 4;
+    const int rows = TT + (p.K - 1) * p.dil;
+    const int in0 = t0 - p.pad;
+    const int S = p.K * NKG;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const unsigned short* xb = p.x + (long long)b * p.T * p.ldx;
+    const int xoff = ((wt * MT) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;  // B-operand base of this lane
+
+    for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
+        if (ci0) __syncthreads();
+        for (int idx = tid; idx < rows * (CK / 8); idx += 256) {
+            const int r = idx / (CK / 8), c = idx % (CK / 8);
+            const int t = in0 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t >= 0 && t < len) v = *(const uint4*)(xb + (long long)t * p.ldx + ci0 + c * 8);
+            *(uint4*)(smem + r * PITCH + c * 16) = v;
+        }
+        __syncthreads();
+        const uint4* wchunk = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;  // (tap 0, first k-group of the chunk)
+        const size_t tap_stride = (size_t)NG * NCT * 64, kg_stride = (size_t)NCT * 64;
+        uint4 ring[R][NT];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int tp = s / NKG, kp = s % NKG;
+            if (s < S) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) ring[s % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
+            }
+        }
+        for (int tap = 0; tap < p.K; ++tap) {
+            const int arow = xoff + tap * p.dil * PITCH;
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                const int s = tap * NKG + kg, sp = s + PF;
+                if (sp < S) {
+                    const int tp = sp / NKG, kp = sp % NKG;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        ring[(kg + PF) % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
+                }
+                uint4 xa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[m] = *(const uint4*)(smem + arow + m * 32 * PITCH + kg * 32);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[kg % R][n],
+                                                                            *(const bf16x8*)&xa[m], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane owns time row (lane & 31) of each tile and 4 consecutive channels per register quad
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = (ct0 + n) * 32 + 8 * q + 4 * (lane >> 5);
+            if (co >= p.C_out) continue;
+            const f32x4 bias = p.bias ? *(const f32x4*)(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool vec = co + 3 < p.C_out;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int t = t0 + (wt * MT + m) * 32 + (lane & 31);
+                if (t >= len) continue;
+                const long long row = (long long)b * p.T + t;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e] + bias[e];
+                if (vec) {
+                    if (p.res) v += *(const f32x4*)(p.res + row * p.ldres + co);
+                    if (p.res2) v += *(const f32x4*)(p.res2 + row * p.ldres2 + co);
+                    if (p.div != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+                    }
+                    if (p.post_tanh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                    }
+                    if (p.yf) *(f32x4*)(p.yf + row * p.ldyf + co) = v;
+                    if (p.ya) {
+                        unsigned h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = vf2bf(v[e] > 0.f ? v[e] : v[e] * p.slope);
+                        *(uint2*)(p.ya + row * p.ldya + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    }
+                } else {
+                    for (int e = 0; e < 4 && co + e < p.C_out; ++e) {
+                        float u = v[e];
+                        if (p.res) u += p.res[row * p.ldres + co + e];
+                        if (p.res2) u += p.res2[row * p.ldres2 + co + e];
+                        if (p.div != 1.f) u = u / p.div;
+                        if (p.post_tanh) u = tanhf(u);
+                        if (p.yf) p.yf[row * p.ldyf + co + e] = u;
+                        if (p.ya) p.ya[row * p.ldya + co + e] = (unsigned short)vf2bf(u > 0.f ? u : u * p.slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int WT, int WC, int CK>
+static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
+    constexpr int PITCH = CK * 2 + 16, TT = 32 * MT * WT, CO_T = 32 * NT * WC;
+    const int rows = TT + (p.K - 1) * p.dil;
+    const size_t lds = (size_t)rows * PITCH;
+    auto kern = vconv_kernel<MT, NT, WT, WC, CK>;
+    static size_t configured = 0;
+    if (lds > 65536 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    if (p.C_out_pad % CO_T || p.C_in_pad % CK) return hipErrorInvalidValue;
+    dim3 grid((p.T + TT - 1) / TT, p.C_out_pad / CO_T, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
+    const int ci = p.C_in_pad, co = p.C_out_pad;
+    if (co % 256 == 0) {
+        if (ci % 128 == 0) return vlaunch<4, 2, 1, 4, 128>(p, stream);
+        if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
+        return vlaunch<4, 2, 1, 4, 32>(p, stream);
+    }
+    if (co == 128) {
+        if (ci % 128 == 0) return vlaunch<4, 1, 1, 4, 128>(p, stream);
+        if (ci % 64 == 0) return vlaunch<4, 1, 1, 4, 64>(p, stream);
+        return vlaunch<4, 1, 1, 4, 32>(p, stream);
+    }
+    if (co == 64) {
+        if (ci % 64 == 0) return vlaunch<4, 1, 2, 2, 64>(p, stream);
+        return vlaunch<4, 1, 2, 2, 32>(p, stream);
+    }
+    if (co == 32) {
+        if (ci % 64 == 0) return vlaunch<4, 1, 4, 1, 64>(p, stream);
+        return vlaunch<4, 1, 4, 1, 32>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// mel fp32 [rows][C] -> bf16 [rows][C_pad] (zero padded channels), no activation
+__global__ void f32_to_bf16_pad_kernel(const float* x, unsigned short* y, long long rows, int C, int C_pad) {
+    const long long n = rows * C_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C_pad;
+        const int c = (int)(i % C_pad);
+        y[i] = c < C ? (unsigned short)vf2bf(x[r * C + c]) : 0;
+    }
+}
+hipError_t f32_to_bf16_pad_launch(const float* x, unsigned short* y, long long rows, int C, int C_pad, hipStream_t s) {
+    const long long n = rows * C_pad;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(blocks), dim3(256), 0, s, x, y, rows, C, C_pad);
+    return hipGetLastError();
+}
+
+} // namespace dtts
