@@ -67,12 +67,13 @@ def cpu_baseline(torch, np, synth, n_utt=6, max_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=60)
     ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of mels when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="debug: per-phase device/host times on stderr")
     args = ap.parse_args()
 
     import numpy as np
@@ -119,16 +120,28 @@ def main():
         mel_all = torch.empty(world * B, CAP, 80, device=dev)
         comm_stream = torch.cuda.Stream(device=dev)
 
+    phase_log = []
+
     def run_step():
         # encode (one host sync: T_mel) -> decode -> vocoder; z_p sliced from the resident noise
         stream = torch.cuda.current_stream().cuda_stream
+        if args.phases:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            h0 = time.perf_counter()
+            ev[0].record()
         ptr = lambda t: t.data_ptr()
         T_mel = m.ctx.text2mel_encode(ptr(batch["word_tokens"]), ptr(batch["keys"]), ptr(batch["values"]),
                                       ptr(batch["key_map"]), ptr(batch["pinyin"]), ptr(batch["pinyin_map"]),
                                       ptr(batch["pron_modified"]), None, B, T_w, L_k, batch["pinyin"].shape[2], stream)
+        if args.phases:
+            h1 = time.perf_counter()
+            ev[1].record()
         z = z_all[:, :, : T_mel // 4].contiguous()
         mel = torch.empty(B, T_mel, 80, device=dev)
         m.ctx.text2mel_decode(z.data_ptr(), mel.data_ptr(), stream)
+        if args.phases:
+            h2 = time.perf_counter()
+            ev[2].record()
         lens = torch.empty(B, dtype=torch.int32, device=dev)
         m.ctx.fetch(abi.OUT_MEL_LENS, lens.data_ptr(), stream)
         work = None
@@ -140,10 +153,17 @@ def main():
         wav = voc.forward_batch(mel, lens)
         if work is not None:
             work.wait()
+        if args.phases:
+            h3 = time.perf_counter()
+            ev[3].record()
+            phase_log.append((ev, (h0, h1, h2, h3)))
         return lens, wav, T_mel
 
-    for _ in range(args.warmup):
+    lens_acc = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(args.warmup):  # identical to the timed loop body (torch lazily loads its reduce/add kernels on first use)
         lens, wav, T_mel = run_step()
+        lens_acc += lens.sum()
+    lens_acc.zero_()
     torch.cuda.synchronize()
     voc.ctx.timer_reset()
     if dist is not None:
@@ -151,7 +171,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frames_rank = 0
-    lens_acc = torch.zeros((), dtype=torch.int64, device=dev)
     for _ in range(args.steps):
         lens, wav, T_mel = run_step()
         lens_acc += lens.sum()
@@ -173,6 +192,15 @@ def main():
         frames_total = frames_rank
     assert torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
 
+    if args.phases and rank == 0:
+        prev_ev = None
+        for ev, hs in phase_log[-args.steps:]:
+            if prev_ev is not None:
+                print("  gap to previous step end (device ms): %.2f" % prev_ev.elapsed_time(ev[0]), file=sys.stderr)
+            prev_ev = ev[3]
+            print("phases: device ms encode %.2f decode %.2f vocoder %.2f | host ms encode %.2f decode %.2f vocoder %.2f" % (
+                ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]),
+                (hs[1] - hs[0]) * 1e3, (hs[2] - hs[1]) * 1e3, (hs[3] - hs[2]) * 1e3), file=sys.stderr)
     if rank == 0:
         value = frames_total / elapsed
         samples = value * voc.hop

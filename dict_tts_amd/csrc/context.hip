@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
@@ -642,6 +643,8 @@ VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* len
     p.pad = L.pad;
     p.slope = 1.f;
     p.div = 1.f;
+    static const int dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
+    p.dbg = dbg;
     return p;
 }
 

@@ -23,6 +23,7 @@ struct VConvParams {
     int ldres2;
     float div;                // 1 or num_kernels (true division)
     int post_tanh;
+    int dbg;                  // tuning ablations (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging
 };
 
 hipError_t vconv_launch(const VConvParams& p, hipStream_t stream);

@@ -26,7 +26,7 @@ __device__ __forceinline__ unsigned vf2bf(float f) {
 }
 
 template <int MT, int NT, int WT, int WC, int CK>
-__global__ __launch_bounds__(256) void vconv_kernel(const VConvParams p) {
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
     constexpr int TT = 32 * MT * WT;
@@ -61,12 +61,26 @@ __global__ __launch_bounds__(256) void vconv_kernel(const VConvParams p) {
 
     for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
         if (ci0) __syncthreads();
-        for (int idx = tid; idx < rows * (CK / 8); idx += 256) {
-            const int r = idx / (CK / 8), c = idx % (CK / 8);
-            const int t = in0 + r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t >= 0 && t < len) v = *(const uint4*)(xb + (long long)t * p.ldx + ci0 + c * 8);
-            *(uint4*)(smem + r * PITCH + c * 16) = v;
+        if (!(p.dbg & 4)) {   // stage the activation tile: batches of U independent 16 B loads in flight per thread, then the LDS writes
+            constexpr int U = 8, PIECES = CK / 8;
+            const int total = rows * PIECES;
+            for (int base = tid; base < total; base += 256 * U) {
+                uint4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    const int r = idx / PIECES, c = idx % PIECES;
+                    const int t = in0 + r;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (idx < total && t >= 0 && t < len) v[u] = *(const uint4*)(xb + (long long)t * p.ldx + ci0 + c * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    const int r = idx / PIECES, c = idx % PIECES;
+                    if (idx < total) *(uint4*)(smem + r * PITCH + c * 16) = v[u];
+                }
+            }
         }
         __syncthreads();
         const uint4* wchunk = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;  // (tap 0, first k-group of the chunk)
@@ -74,81 +88,135 @@ __global__ __launch_bounds__(256) void vconv_kernel(const VConvParams p) {
         uint4 ring[R][NT];
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
-            const int tp = s / NKG, kp = s % NKG;
-            if (s < S) {
+            const int sc = s < S ? s : S - 1;
+            const int tp = sc / NKG, kp = sc % NKG;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) ring[s % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
-            }
+            for (int n = 0; n < NT; ++n) ring[s % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
         }
-        for (int tap = 0; tap < p.K; ++tap) {
+        // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s
+        uint4 xa[2][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(smem + xoff + m * 32 * PITCH);
+        for (int tap = 0; tap < ((p.dbg & 1) ? 0 : p.K); ++tap) {
             const int arow = xoff + tap * p.dil * PITCH;
+            const int arow_next = xoff + (tap + 1 < p.K ? tap + 1 : tap) * p.dil * PITCH;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
-                const int s = tap * NKG + kg, sp = s + PF;
-                if (sp < S) {
+                {   // weight prefetch, PF steps ahead (clamped at the end: branch-free body)
+                    int sp = tap * NKG + kg + PF;
+                    sp = sp < S ? sp : S - 1;
                     const int tp = sp / NKG, kp = sp % NKG;
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         ring[(kg + PF) % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
                 }
-                uint4 xa[MT];
+                {
+                    const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow_next;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xa[m] = *(const uint4*)(smem + arow + m * 32 * PITCH + kg * 32);
+                    for (int m = 0; m < MT; ++m) xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[kg % R][n],
-                                                                            *(const bf16x8*)&xa[m], acc[m][n], 0, 0, 0);
+                                                                            *(const bf16x8*)&xa[kg & 1][m], acc[m][n], 0, 0, 0);
             }
         }
     }
 
-    // ---- epilogue: lane owns time row (lane & 31) of each tile and 4 consecutive channels per register quad
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) p.yf[0] = 1.f;
+        return;
+    }
+    // ---- epilogue.  The accumulators are D[co][t] (lane = one time row, 4 consecutive channels per register
+    // quad).  Stored straight from that layout every wave instruction would touch 32 different rows with 32 B each;
+    // instead each 32-row slab goes through LDS (the activation tile is dead by now) and leaves as whole rows:
+    // consecutive lanes -> consecutive 16 B of one row, for the residual loads and both stores.
+    if ((p.C_out & 3) == 0) {
+        constexpr int EP = CO_T * 4 + 16;  // bytes per staged row (+16: conflict-free ds_write_b128)
+        constexpr int F4 = CO_T / 4, TOTAL = WT * 32 * F4, PER = TOTAL / 256;
+        const int co_blk = blockIdx.y * CO_T;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m) __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
+                    const f32x4 bias = p.bias ? *(const f32x4*)(p.bias + co_blk + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e] + bias[e];
+                    *(f32x4*)(smem + (wt * 32 + (lane & 31)) * EP + col * 4) = v;
+                }
+            __syncthreads();
+            constexpr int UB = PER < 4 ? PER : 4;  // loads in flight per thread per batch (bounds VGPR use)
+#pragma unroll
+            for (int u0 = 0; u0 < PER; u0 += UB) {
+                f32x4 v[UB], r1[UB];
+                long long off[UB];
+                bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int idx = tid + (u0 + u) * 256;
+                    const int rl = idx / F4, c4 = idx % F4;
+                    const int t = t0 + ((rl >> 5) * MT + m) * 32 + (rl & 31);
+                    const int co = co_blk + c4 * 4;
+                    ok[u] = t < len && co < p.C_out;
+                    off[u] = ((long long)b * p.T + t);
+                    v[u] = *(const f32x4*)(smem + rl * EP + c4 * 16);
+                    r1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[u] && p.res) r1[u] = *(const f32x4*)(p.res + off[u] * p.ldres + co);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (!ok[u]) continue;
+                    const int co = co_blk + ((tid + (u0 + u) * 256) % F4) * 4;
+                    f32x4 o = v[u] + r1[u];
+                    if (p.res2) o += *(const f32x4*)(p.res2 + off[u] * p.ldres2 + co);
+                    if (p.div != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
+                    }
+                    if (p.post_tanh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]);
+                    }
+                    if (p.yf) *(f32x4*)(p.yf + off[u] * p.ldyf + co) = o;
+                    if (p.ya) {
+                        unsigned h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = vf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
+                        *(uint2*)(p.ya + off[u] * p.ldya + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // C_out not a multiple of 4 (conv_post, C_out = 1): scalar stores; with ld = 1 the 32 rows of a tile are contiguous
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co = (ct0 + n) * 32 + 8 * q + 4 * (lane >> 5);
             if (co >= p.C_out) continue;
-            const f32x4 bias = p.bias ? *(const f32x4*)(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const bool vec = co + 3 < p.C_out;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int t = t0 + (wt * MT + m) * 32 + (lane & 31);
                 if (t >= len) continue;
                 const long long row = (long long)b * p.T + t;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e] + bias[e];
-                if (vec) {
-                    if (p.res) v += *(const f32x4*)(p.res + row * p.ldres + co);
-                    if (p.res2) v += *(const f32x4*)(p.res2 + row * p.ldres2 + co);
-                    if (p.div != 1.f) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
-                    }
-                    if (p.post_tanh) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-                    }
-                    if (p.yf) *(f32x4*)(p.yf + row * p.ldyf + co) = v;
-                    if (p.ya) {
-                        unsigned h[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = vf2bf(v[e] > 0.f ? v[e] : v[e] * p.slope);
-                        *(uint2*)(p.ya + row * p.ldya + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    }
-                } else {
-                    for (int e = 0; e < 4 && co + e < p.C_out; ++e) {
-                        float u = v[e];
-                        if (p.res) u += p.res[row * p.ldres + co + e];
-                        if (p.res2) u += p.res2[row * p.ldres2 + co + e];
-                        if (p.div != 1.f) u = u / p.div;
-                        if (p.post_tanh) u = tanhf(u);
-                        if (p.yf) p.yf[row * p.ldyf + co + e] = u;
-                        if (p.ya) p.ya[row * p.ldya + co + e] = (unsigned short)vf2bf(u > 0.f ? u : u * p.slope);
-                    }
+                for (int e = 0; e < 4 && co + e < p.C_out; ++e) {
+                    float u = acc[m][n][4 * q + e] + (p.bias ? p.bias[co + e] : 0.f);
+                    if (p.res) u += p.res[row * p.ldres + co + e];
+                    if (p.res2) u += p.res2[row * p.ldres2 + co + e];
+                    if (p.div != 1.f) u = u / p.div;
+                    if (p.post_tanh) u = tanhf(u);
+                    if (p.yf) p.yf[row * p.ldyf + co + e] = u;
+                    if (p.ya) p.ya[row * p.ldya + co + e] = (unsigned short)vf2bf(u > 0.f ? u : u * p.slope);
                 }
             }
         }
@@ -159,7 +227,9 @@ template <int MT, int NT, int WT, int WC, int CK>
 static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
     constexpr int PITCH = CK * 2 + 16, TT = 32 * MT * WT, CO_T = 32 * NT * WC;
     const int rows = TT + (p.K - 1) * p.dil;
-    const size_t lds = (size_t)rows * PITCH;
+    size_t lds = (size_t)rows * PITCH;
+    const size_t ep = (size_t)WT * 32 * (CO_T * 4 + 16);
+    if (ep > lds) lds = ep;
     auto kern = vconv_kernel<MT, NT, WT, WC, CK>;
     static size_t configured = 0;
     if (lds > 65536 && lds > configured) {
