@@ -18,6 +18,7 @@
 #include "conv1d.h"
 #include "ops.h"
 #include "vconv.h"
+#include "rblock.h"
 
 using namespace dtts;
 
@@ -116,6 +117,7 @@ struct dtts_ctx {
     PackedConv conv_pre, conv_post;
     std::vector<PackedConv> ups;
     std::vector<std::vector<PackedConv>> rb1, rb2;  // [resblock][3]
+    std::vector<std::vector<PackedConv>> rbf1, rbf2;  // fused-ResBlock copies (taps zero padded), empty where unsupported
     int hop = 1;
     // ---- workspaces and per-call state
     Arena a_enc, a_dec, a_voc;
@@ -486,6 +488,33 @@ int build_vocoder(dtts_ctx* h) {
             ok = ok && pack_plain(h, need, h->rb2[i][mth], eng, r + ".convs2." + std::to_string(mth), 1, 1, (k - 1) / 2);
         }
     }
+    // fused ResBlock kernel (bf16 mode, narrow stages): the same weights with the tap axis zero padded so that the
+    // number of k-steps is a multiple of the register ring depth
+    h->rbf1.assign((size_t)c.n_upsamples * nk, {});
+    h->rbf2.assign((size_t)c.n_upsamples * nk, {});
+    for (int i = 0; ok && eng == ENG_BF16 && i < c.n_upsamples * nk; ++i) {
+        const int j = i % nk, k = c.resblock_kernel_sizes[j];
+        const int ch = c.upsample_initial_channel >> (i / nk + 1);
+        if (!rblock_supported(ch, k)) continue;
+        const int kp = rblock_padded_taps(ch, k);
+        h->rbf1[i].resize(3);
+        h->rbf2[i].resize(3);
+        for (int mth = 0; ok && mth < 3; ++mth) {
+            const std::string r = v + "resblocks." + std::to_string(i);
+            for (int which = 0; which < 2 && ok; ++which) {
+                const std::string base = r + (which ? ".convs2." : ".convs1.") + std::to_string(mth);
+                const HostTensor* w = folded_weight(h, need, base);
+                std::vector<float> bias = bias_of(need, base);
+                if (!w || bias.empty()) { ok = false; break; }
+                const float* pw = w->f.data();
+                PackedConv& L = which ? h->rbf2[i][mth] : h->rbf1[i][mth];
+                ok = pack_conv(h, L, ENG_BF16, ch, ch, kp,
+                               [=](int co, int ci, int tap) { return tap < k ? pw[((size_t)co * ch + ci) * k + tap] : 0.f; }, bias,
+                               which ? 1 : c.resblock_dilation_sizes[j][mth], 1, 0);
+                L.K = k;
+            }
+        }
+    }
     ok = ok && pack_plain(h, need, h->conv_post, eng, v + "conv_post", 1, 1, 3);
     if (!ok) {
         if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
@@ -686,6 +715,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
     }
     HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
     const int TV = DTTS_TIMER_VOC_CONV;
+    const bool fuse = !(getenv("DTTS_VOC_FUSE") && atoi(getenv("DTTS_VOC_FUSE")) == 0);  // tuning / A-B switch
     LAUNCH(f32_to_bf16_pad_launch(mel, melb, (long long)B * T, c.audio_num_mel_bins, melC, s));
     int Tcur = T, ch = c.upsample_initial_channel;
     {   // conv_pre: only its leaky_relu(0.1) bf16 copy is consumed (by ups[0])
@@ -716,6 +746,35 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
         for (int j = 0; j < nk; ++j) {
             const auto& c1 = h->rb1[(size_t)i * nk + j];
             const auto& c2 = h->rb2[(size_t)i * nk + j];
+            if (fuse && !h->rbf1[(size_t)i * nk + j].empty()) {   // whole ResBlock in one kernel (rblock.hip)
+                const auto& f1 = h->rbf1[(size_t)i * nk + j];
+                const auto& f2 = h->rbf2[(size_t)i * nk + j];
+                RBlockParams rp;
+                memset(&rp, 0, sizeof rp);
+                rp.x = Xf;
+                rp.S = Sf;
+                rp.lens = lout;
+                rp.B = B;
+                rp.T = Tcur;
+                rp.K = f1[0].K;
+                rp.Kp = rblock_padded_taps(ch, f1[0].K);
+                for (int mth = 0; mth < 3; ++mth) {
+                    rp.w1[mth] = (const uint4*)f1[mth].w_hi;
+                    rp.w2[mth] = (const uint4*)f2[mth].w_hi;
+                    rp.b1[mth] = f1[mth].bias;
+                    rp.b2[mth] = f2[mth].bias;
+                    rp.dil[mth] = f1[mth].dil;
+                }
+                rp.mode = j == 0 ? 0 : (j == nk - 1 ? 2 : 1);
+                if (nk == 1) rp.mode = 2;
+                rp.div = (float)nk;
+                rp.slope = last_stage ? 0.01f : 0.1f;
+                rp.Sa = Sa;
+                if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
+                Timed tm(h, TV, s);
+                LAUNCH(rblock_launch(rp, ch, s));
+                continue;
+            }
             for (int mth = 0; mth < 3; ++mth) {
                 {   // xt = c1(leaky_relu(x)); only leaky_relu(xt) in bf16 is ever consumed
                     VConvParams p = vparams(c1[mth], mth == 0 ? Xa : Ra, lout, B, Tcur);

@@ -1,0 +1,27 @@
+// Fused HifiGAN ResBlock1 kernel for the narrow stages: see rblock.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dtts {
+
+struct RBlockParams {
+    const float* x;        // stage input, fp32 [B][T][C] (the transposed conv's output)
+    float* S;              // stage accumulator xs, fp32 [B][T][C]
+    unsigned short* Sa;    // bf16 leaky_relu(xs / num_kernels, slope): next stage's input (mode 2 only)
+    const uint4* w1[3];    // convs1[m] / convs2[m] packed weights, Kp taps (zero padded)
+    const uint4* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    int dil[3];
+    const int* lens;       // [B] valid rows
+    int B, T, K, Kp;
+    int mode;              // 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
+    float div, slope;
+};
+
+bool rblock_supported(int C, int K);
+int rblock_padded_taps(int C, int K);
+hipError_t rblock_launch(const RBlockParams& p, int C, hipStream_t stream);
+
+} // namespace dtts

@@ -1,0 +1,262 @@
+// Fused HifiGAN ResBlock1 (modules/hifigan/hifigan.py:27-58) for the narrow stages (C = 64, 32), bf16 MFMA.
+//
+// Unfused, a ResBlock is six convolutions that each stream the whole activation through HBM; at C <= 64 their
+// arithmetic intensity (C*k/2 FLOP/B) is far below the MFMA/HBM ridge, i.e. the vocoder's last two stages (36 % of
+// its FLOPs) are HBM-bound.  Here one workgroup keeps a time tile resident for all six convolutions:
+//   * the fp32 residual stream x lives in REGISTERS in MFMA accumulator layout (D[co][t]),
+//   * the bf16 leaky_relu copy that feeds the next convolution lives in ONE LDS buffer (A and the intermediate
+//     xt time-share it: conv reads -> barrier -> overwrite -> barrier),
+//   * weights stream from L2 through a 4-deep register ring (22..90 KB per conv, shared by every workgroup),
+//   * the tile carries a halo of 6*(k-1) rows per side (sum of the six receptive half-widths) that is recomputed;
+//     rows outside the utterance are forced to zero after every activation = the reference's zero padding.
+// HBM traffic per ResBlock drops from ~9 passes to: read x once, read-modify-write the stage accumulator once.
+#include "rblock.h"
+
+namespace dtts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned rf2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+constexpr int RB_GUARD = 32;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap of dilation 5)
+
+// acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]
+template <int MT, int NT, int NKG, int PITCH>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], const char* act, int xrow0, const uint4* w, int S, int dilP,
+                                            int kg_stride) {
+    uint4 ring[4][NT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kg_stride + n * 64];
+    uint4 xa[2][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
+    for (int s0 = 0; s0 < S; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            {
+                const int sp = (s + 3 < S) ? s + 3 : S - 1;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = w[(size_t)sp * kg_stride + n * 64];
+            }
+            {
+                const int sn = (s + 1 < S) ? s + 1 : S - 1;
+                const int off = xrow0 + (sn / NKG) * dilP + (sn % NKG) * 32;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
+                                                                        acc[m][n], 0, 0, 0);
+        }
+    }
+}
+
+template <int C, int MT, int NT, int WT, int WC>
+__global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams p) {
+    static_assert(WC * NT * 32 == C, "channel tiling must cover C");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int THREADS = 64 * WT * WC;
+    constexpr int W = 32 * MT * WT;
+    constexpr int PITCH = C * 2 + 16;
+    constexpr int NKG = C / 16;
+    constexpr int EP = C * 4 + 16;                 // fp32 staging row
+    constexpr int F4 = C / 4, SROWS = WT * 32;
+    char* act = smem;
+    char* stage = smem + (size_t)(W + 2 * RB_GUARD) * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % WT, wc = wave / WT;
+    const int b = blockIdx.y;
+    const int H = 6 * (p.K - 1);
+    const int TT = W - 2 * H;
+    const int t0 = blockIdx.x * TT;
+    const int len = p.lens ? p.lens[b] : p.T;
+    if (t0 >= len) return;
+    const int base_t = t0 - H;  // global time of local row 0
+    const long long brow = (long long)b * p.T;
+
+    // zero the guard bands once
+    for (int idx = tid; idx < 2 * RB_GUARD * (PITCH / 16); idx += THREADS) {
+        const int r = idx / (PITCH / 16), c = idx % (PITCH / 16);
+        const int row = r < RB_GUARD ? r : W + r;
+        *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- load the fp32 residual stream into accumulator layout (coalesced global -> LDS -> fragments)
+    f32x16 xr[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m) __syncthreads();
+        for (int idx = tid; idx < SROWS * F4; idx += THREADS) {
+            const int rl = idx / F4, c4 = idx % F4;
+            const int t = base_t + ((rl >> 5) * MT + m) * 32 + (rl & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < len) v = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+            *(f32x4*)(stage + rl * EP + c4 * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] = v[e];
+            }
+    }
+
+    // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance
+    auto write_act = [&](const f32x16 (&v)[MT][NT], const float* bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = (wt * MT + m) * 32 + (lane & 31);
+            const int t = base_t + row;
+            const bool inb = t >= 0 && t < len;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
+                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) bb = *(const f32x4*)(bias + co);
+                    unsigned h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = v[m][n][4 * q + e] + bb[e];
+                        a = a > 0.f ? a : a * 0.1f;
+                        h[e] = inb ? rf2bf(a) : 0u;
+                    }
+                    *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                }
+        }
+    };
+
+    write_act(xr, nullptr);
+    __syncthreads();
+
+    const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+    const int kg_stride = (C / 32) * 64;
+    const int S = p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
+    f32x16 acc[MT][NT];
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int d = p.dil[it];
+        rb_contract<MT, NT, NKG, PITCH>(acc, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + (size_t)(wc * NT) * 64 + lane, S,
+                                        d * PITCH, kg_stride);
+        __syncthreads();               // every wave is done reading A
+        write_act(acc, p.b1[it]);      // xt (bf16, activated) overwrites it
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        rb_contract<MT, NT, NKG, PITCH>(acc, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + (size_t)(wc * NT) * 64 + lane, S, PITCH,
+                                        kg_stride);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *(const f32x4*)(p.b2[it] + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += acc[m][n][4 * q + e] + bb[e];  // x = xt + x
+            }
+        __syncthreads();               // every wave is done reading xt
+        if (it < 2) {
+            write_act(xr, nullptr);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: rows [H, H+TT) of the tile leave as whole rows through the fp32 staging buffer
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m) __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xr[m][n][4 * q + e];
+                *(f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+            }
+        __syncthreads();
+        for (int idx = tid; idx < SROWS * F4; idx += THREADS) {
+            const int rl = idx / F4, c4 = idx % F4;
+            const int row = ((rl >> 5) * MT + m) * 32 + (rl & 31);
+            const int t = base_t + row;
+            if (row < H || row >= H + TT || t >= len) continue;
+            f32x4 o = *(const f32x4*)(stage + rl * EP + c4 * 16);
+            float* dst = p.S + (brow + t) * C + c4 * 4;
+            if (p.mode >= 1) o += *(const f32x4*)dst;   // xs += resblock(x)  (hifigan.py:133-135)
+            if (p.mode == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
+            }
+            *(f32x4*)dst = o;
+            if (p.mode == 2 && p.Sa) {
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = rf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
+                *(uint2*)(p.Sa + (brow + t) * C + c4 * 4) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+}
+
+template <int C, int MT, int NT, int WT, int WC>
+static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
+    constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
+    const int H = 6 * (p.K - 1), TT = W - 2 * H;
+    if (TT < 32) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
+    auto kern = rblock_kernel<C, MT, NT, WT, WC>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.T + TT - 1) / TT, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WT * WC), lds, stream, p);
+    return hipGetLastError();
+}
+
+bool rblock_supported(int C, int K) { return (C == 32 || C == 64) && K >= 3 && K <= 11 && (K & 1); }
+
+int rblock_padded_taps(int C, int K) {
+    const int nkg = C / 16;
+    int kp = K;
+    while ((kp * nkg) % 4) ++kp;
+    return kp;
+}
+
+hipError_t rblock_launch(const RBlockParams& p, int C, hipStream_t stream) {
+    if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1>(p, stream);   // 512-row tile, 4 waves over time
+    if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2>(p, stream);   // 512-row tile, 8 waves (4 time x 2 channel)
+    return hipErrorInvalidValue;
+}
+
+} // namespace dtts

@@ -198,3 +198,25 @@ def test_missing_weight_fails_loudly(voc_sd):
     ctx = abi.Context()
     with pytest.raises(abi.DttsError, match="before a successful"):
         ctx.text2mel_decode(1, 1, None)
+
+
+def test_fused_resblock_equals_unfused(voc_bf16):
+    """the fused ResBlock kernel (rblock.hip, stages with C <= 64) and the per-convolution path have the same rounding
+    points (bf16 conv inputs, fp32 accumulation / residual), so they agree to fp32 summation-order noise; lengths
+    straddle the fused kernel's time tiles (392/440/488 rows at C=32, x256 samples per frame)"""
+    lens = [3, 50, 97]
+    mels = [synth.random_mel(300 + i, n, f"fuse{i}") for i, n in enumerate(lens)]
+    old = os.environ.get("DTTS_VOC_FUSE")
+    try:
+        os.environ["DTTS_VOC_FUSE"] = "1"
+        a = voc_bf16.spec2wav_batch(mels)
+        os.environ["DTTS_VOC_FUSE"] = "0"
+        b = voc_bf16.spec2wav_batch(mels)
+    finally:
+        if old is None:
+            os.environ.pop("DTTS_VOC_FUSE", None)
+        else:
+            os.environ["DTTS_VOC_FUSE"] = old
+    for x, y, n in zip(a, b, lens):
+        assert x.shape == y.shape == (n * 256,)
+        assert np.abs(x - y).max() <= 2e-5, np.abs(x - y).max()
