@@ -770,6 +770,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 rp.div = (float)nk;
                 rp.slope = last_stage ? 0.01f : 0.1f;
                 rp.Sa = Sa;
+                rp.dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) >> 4 : 0;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
                 LAUNCH(rblock_launch(rp, ch, s));

@@ -17,10 +17,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __forceinline__ unsigned f2bf(float f) {  // round-to-nearest-even fp32 -> bf16 (bits)
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+__device__ __forceinline__ unsigned f2bf(float f) {  // round-to-nearest-even fp32 -> bf16 bits (hardware convert)
+    const __bf16 h = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 

@@ -18,6 +18,7 @@ struct RBlockParams {
     int B, T, K, Kp;
     int mode;              // 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
     float div, slope;
+    int dbg;               // tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };
 
 bool rblock_supported(int C, int K);

@@ -18,10 +18,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __forceinline__ unsigned rf2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+__device__ __forceinline__ unsigned rf2bf(float f) {  // round-to-nearest-even fp32 -> bf16 bits (hardware convert)
+    const __bf16 h = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
 constexpr int RB_GUARD = 32;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap of dilation 5)
@@ -53,12 +52,14 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], const char* a
 #pragma unroll
                 for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads / weight load ABOVE this step's MFMAs
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
                                                                         acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
             const int rl = idx / F4, c4 = idx % F4;
             const int t = base_t + ((rl >> 5) * MT + m) * 32 + (rl & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < len) v = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+            if (t >= 0 && t < len && !(p.dbg & 4)) v = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
             *(f32x4*)(stage + rl * EP + c4 * 16) = v;
         }
         __syncthreads();
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 
     // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance
     auto write_act = [&](const f32x16 (&v)[MT][NT], const float* bias) {
+        if (p.dbg & 8) return;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = (wt * MT + m) * 32 + (lane & 31);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 
     const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const int kg_stride = (C / 32) * 64;
-    const int S = p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
+    const int S = (p.dbg & 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
     f32x16 acc[MT][NT];
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -189,6 +191,10 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         }
     }
 
+    if (p.dbg & 2) {
+        if (xr[0][0][0] == 123.456f) p.S[0] = 1.f;
+        return;
+    }
     // ---- epilogue: rows [H, H+TT) of the tile leave as whole rows through the fp32 staging buffer
 #pragma unroll
     for (int m = 0; m < MT; ++m) {

@@ -19,10 +19,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __forceinline__ unsigned vf2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+__device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even fp32 -> bf16 bits (hardware convert)
+    const __bf16 h = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
 template <int MT, int NT, int WT, int WC, int CK>
@@ -115,12 +114,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
 #pragma unroll
                     for (int m = 0; m < MT; ++m) xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // the prefetches above stay above this step's MFMAs
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[kg % R][n],
                                                                             *(const bf16x8*)&xa[kg & 1][m], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
