@@ -95,27 +95,41 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // ---- load the fp32 residual stream into accumulator layout (coalesced global -> LDS -> fragments)
+    // ---- load the fp32 residual stream into accumulator layout (coalesced global -> LDS -> fragments).  All
+    // MT*PER 16 B loads of a thread are issued before the first LDS round trip: one exposed HBM latency per tile.
+    constexpr int PER = SROWS * F4 / THREADS;
+    static_assert(SROWS * F4 % THREADS == 0, "staging pass must divide evenly");
     f32x16 xr[MT][NT];
+    {
+        f32x4 ld[MT][PER];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m) __syncthreads();
-        for (int idx = tid; idx < SROWS * F4; idx += THREADS) {
-            const int rl = idx / F4, c4 = idx % F4;
-            const int t = base_t + ((rl >> 5) * MT + m) * 32 + (rl & 31);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < len && !(p.dbg & 4)) v = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
-            *(f32x4*)(stage + rl * EP + c4 * 16) = v;
-        }
-        __syncthreads();
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] = v[e];
+            for (int u = 0; u < PER; ++u) {
+                const int idx = tid + u * THREADS;
+                const int rl = idx / F4, c4 = idx % F4;
+                const int t = base_t + ((rl >> 5) * MT + m) * 32 + (rl & 31);
+                ld[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < len && !(p.dbg & 4)) ld[m][u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
             }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m) __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int idx = tid + u * THREADS;
+                *(f32x4*)(stage + (idx / F4) * EP + (idx % F4) * 16) = ld[m][u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *(const f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] = v[e];
+                }
+        }
     }
 
     // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance
@@ -195,7 +209,20 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         if (xr[0][0][0] == 123.456f) p.S[0] = 1.f;
         return;
     }
-    // ---- epilogue: rows [H, H+TT) of the tile leave as whole rows through the fp32 staging buffer
+    // ---- epilogue: rows [H, H+TT) of the tile leave as whole rows through the fp32 staging buffer; the old
+    // accumulator values (xs += ...) of all MT passes are fetched up front
+    f32x4 sold[MT][PER];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * THREADS;
+            const int rl = idx / F4, c4 = idx % F4;
+            const int row = ((rl >> 5) * MT + m) * 32 + (rl & 31);
+            const int t = base_t + row;
+            sold[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.mode >= 1 && row >= H && row < H + TT && t < len) sold[m][u] = *(const f32x4*)(p.S + (brow + t) * C + c4 * 4);
+        }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (m) __syncthreads();
@@ -209,14 +236,16 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
                 *(f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
             }
         __syncthreads();
-        for (int idx = tid; idx < SROWS * F4; idx += THREADS) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * THREADS;
             const int rl = idx / F4, c4 = idx % F4;
             const int row = ((rl >> 5) * MT + m) * 32 + (rl & 31);
             const int t = base_t + row;
             if (row < H || row >= H + TT || t >= len) continue;
             f32x4 o = *(const f32x4*)(stage + rl * EP + c4 * 16);
             float* dst = p.S + (brow + t) * C + c4 * 4;
-            if (p.mode >= 1) o += *(const f32x4*)dst;   // xs += resblock(x)  (hifigan.py:133-135)
+            o += sold[m][u];                             // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
             if (p.mode == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
