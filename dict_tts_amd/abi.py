@@ -19,7 +19,7 @@ TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
 EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_text2mel_encode", "dtts_text2mel_decode", "dtts_text2mel_fetch",
-           "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
+           "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
 
 
 class DttsConfig(C.Structure):
@@ -66,6 +66,7 @@ def load_library(path=None):
     lib.dtts_text2mel_decode.argtypes = [vp, vp, vp, vp]
     lib.dtts_text2mel_fetch.argtypes = [vp, i32, vp, vp]
     lib.dtts_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.dtts_length_regulate.argtypes = [vp, vp, vp, i32, i32, vp, i32, C.POINTER(C.c_int32), vp]
     lib.dtts_hifigan_hop.argtypes = [vp]
     lib.dtts_timer_enable.argtypes = [vp, i32]
     lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -140,6 +141,12 @@ class Context:
 
     def fetch(self, what, dst, stream):
         self._chk(self.lib.dtts_text2mel_fetch(self.h, what, dst, stream), "dtts_text2mel_fetch")
+
+    def length_regulate(self, dur, ilens, B, T_w, mel2word, cap, stream):
+        t_max = C.c_int32(0)
+        self._chk(self.lib.dtts_length_regulate(self.h, dur, ilens, B, T_w, mel2word, cap, C.byref(t_max), stream),
+                  "dtts_length_regulate")
+        return t_max.value
 
     def hifigan_forward(self, mel, lens, B, T, wav, stream):
         self._chk(self.lib.dtts_hifigan_forward(self.h, mel, lens or None, B, T, wav, stream), "dtts_hifigan_forward")

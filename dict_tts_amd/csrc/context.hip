@@ -1271,6 +1271,33 @@ int dtts_text2mel_fetch(dtts_handle h, int what, void* dst, dtts_stream stream) 
     return DTTS_OK;
 }
 
+int dtts_length_regulate(dtts_handle h, const float* dur, const int32_t* ilens, int B, int T_w, int64_t* mel2word, int cap,
+                         int32_t* T_max_host, dtts_stream stream) {
+    if (!h || !dur || !ilens || !mel2word || !T_max_host || B <= 0 || T_w <= 0 || cap <= 0)
+        return fail(h, DTTS_E_INVAL, "dtts_length_regulate: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int *starts = nullptr, *total = nullptr;
+    HIPCHK(hipMalloc((void**)&starts, sizeof(int) * ((size_t)B * (T_w + 1) + B)));
+    total = starts + (size_t)B * (T_w + 1);
+    std::vector<int> tot(B);
+    hipError_t e = durations_launch(dur, ilens, starts, total, B, T_w, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(tot.data(), total, sizeof(int) * B, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int T_raw = 0;
+    for (int b = 0; b < B; ++b) T_raw = std::max(T_raw, tot[b]);
+    *T_max_host = T_raw;
+    int rc = DTTS_OK;
+    if (e != hipSuccess) rc = fail(h, DTTS_E_HIP, "dtts_length_regulate: %s", hipGetErrorString(e));
+    else if (T_raw > cap) rc = fail(h, DTTS_E_INVAL, "dtts_length_regulate: %d frames exceed the capacity %d", T_raw, cap);
+    else {
+        e = mel2word_fill_launch(starts, total, ilens, mel2word, B, T_w, cap, cap, s);  // columns >= total[b] are zero
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(h, DTTS_E_HIP, "dtts_length_regulate: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(starts);
+    return rc;
+}
+
 int dtts_timer_enable(dtts_handle h, int which) {
     if (!h || which < 1 || which > 2) return DTTS_E_INVAL;
     h->timers[which].enabled = true;

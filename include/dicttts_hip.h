@@ -135,6 +135,16 @@ int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev
 int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stream);
 
 /*
+ * Length regulator alone — replaces the integer part of add_dur + LengthRegulator.forward
+ * (modules/dict_tts/model.py:78-81, modules/fastspeech/tts_modules.py:215-251): dur [B,T_w] f32 (log domain),
+ * ilens [B] i32 valid words; d = clamp(round_half_even(exp(dur) - 1), 0), an utterance whose durations are all zero
+ * gets ones.  Writes mel2word [B,cap] i64 (1-based word index, 0 = padding; columns beyond the longest utterance
+ * are zero) and, on the host, the per-batch maximum frame count (unpadded).  Returns DTTS_E_INVAL if it exceeds cap.
+ */
+int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ilens_dev, int B, int T_w, int64_t* mel2word_dev,
+                         int cap, int32_t* T_max_host, dtts_stream stream);
+
+/*
  * Vocoder — replaces HifiGanGenerator.forward as used by HifiGAN.spec2wav (vocoders/hifigan.py:54-62), for a
  * batch: mel [B,T,80] f32 (the layout of ret['mel_out'] and of spec2wav's argument), lens [B] i32 valid
  * frames per utterance (NULL = T for all).  wav [B, T*hop] f32; utterance b is exactly what the reference

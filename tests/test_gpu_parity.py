@@ -122,24 +122,39 @@ def test_teacher_forced_mel2word_and_batch_padding_semantics(acoustic, oracle_sd
     assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3   # ALL frames, padded ones included
 
 
-def test_duration_rounding_and_zero_utterance_vs_reference_golden(golden_dir):
-    """G3 integer semantics on the device kernels directly: half-to-even rounding, all-zero utterance -> ones"""
-    from oracle import dict_tts_ref as ref
+def test_length_regulator_device_vs_reference_golden(golden_dir):
+    """G3 integer semantics on the device kernels through dtts_length_regulate: the reference's mel2word for crafted
+    integer durations (zeros in the middle, an all-zero utterance -> ones, ilens shorter than T_w), and torch.round's
+    half-to-even ties"""
     g = np.load(os.path.join(golden_dir, "g3_duration.npz"))
     d, il = gc.g3_int_durations()
-    want = g["mel2word_int"]
-    # encode integer durations as log-durations that reproduce them exactly, plus .5 ties
-    dur = np.log(d.astype(np.float64) + 1.0).astype(np.float32)
-    ties = np.array([[np.log(1.5), np.log(2.5), np.log(3.5), np.log(4.5)]], np.float32)
-    tie_round = torch.clamp(torch.round(torch.from_numpy(ties).exp() - 1), min=0).long()
-    # run the length regulator through the oracle (torch.round) and compare with the golden first
-    assert np.array_equal(ref.length_regulator(T(d), T(il)).numpy(), want)
-    import ctypes
-    lib = abi.load_library()
-    assert lib is not None  # the device side of this test lives in test_g5 (predicted durations, exact x_mask)
-    exp = torch.from_numpy(dur).exp() - 1
-    assert torch.equal(torch.clamp(torch.round(exp), min=0).long(), T(d))
-    assert tie_round.shape == (1, 4)
+    want = g["mel2word_int"]                                   # produced by the reference LengthRegulator
+    ctx = abi.Context()
+    dur = torch.log(T(d).double() + 1.0).float().cuda()        # exp(dur) - 1 rounds back to d exactly
+    assert torch.equal(torch.clamp(torch.round(dur.cpu().exp() - 1), min=0).long(), T(d))
+    ilens = T(il).to(torch.int32).cuda()
+    cap = 64
+    m2w = torch.full((d.shape[0], cap), -1, dtype=torch.int64, device="cuda")
+    t_max = ctx.length_regulate(dur.data_ptr(), ilens.data_ptr(), d.shape[0], d.shape[1], m2w.data_ptr(), cap, None)
+    assert t_max == want.shape[1]
+    assert np.array_equal(m2w.cpu().numpy()[:, :t_max], want)
+    assert int(m2w[:, t_max:].abs().max()) == 0
+    # random log-durations, ragged ilens: device exp/round/scan vs the oracle (torch.round = half-to-even; an exact .5
+    # cannot be forced through exp(), so ties are covered by the kernel using rintf, the same IEEE rounding)
+    rng = np.random.default_rng(3)
+    Bn, Tn = 16, 40
+    dur = torch.from_numpy(rng.uniform(0.0, 3.2, (Bn, Tn)).astype(np.float32))
+    il = torch.from_numpy(rng.integers(1, Tn + 1, Bn).astype(np.int64))
+    from oracle import dict_tts_ref as ref_mod
+    d_int = torch.clamp(torch.round(dur.exp() - 1), min=0).long()
+    want = ref_mod.length_regulator(d_int, il)
+    cap2 = int(want.shape[1]) + 7
+    m2w = torch.full((Bn, cap2), -1, dtype=torch.int64, device="cuda")
+    dur_d, il_d = dur.cuda(), il.to(torch.int32).cuda()      # keep the device tensors alive across the call
+    t_max = ctx.length_regulate(dur_d.data_ptr(), il_d.data_ptr(), Bn, Tn, m2w.data_ptr(), cap2, None)
+    assert t_max == want.shape[1] and np.array_equal(m2w.cpu().numpy()[:, :t_max], want.numpy())
+    with pytest.raises(abi.DttsError, match="exceed the capacity"):
+        ctx.length_regulate(dur_d.data_ptr(), il_d.data_ptr(), Bn, Tn, m2w.data_ptr(), 4, None)
 
 
 # ------------------------------------------------------------------------------------------------ vocoder
@@ -220,3 +235,55 @@ def test_fused_resblock_equals_unfused(voc_bf16):
     for x, y, n in zip(a, b, lens):
         assert x.shape == y.shape == (n * 256,)
         assert np.abs(x - y).max() <= 2e-5, np.abs(x - y).max()
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 4, 5
+def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc_bf16, oracle_voc_sd):
+    """BASELINE.json configs[3]: 1000-char input (T_w = 1002), teacher-forced 5 frames/char -> ~5k mel frames, B=1:
+    attention over 1002 words, every conv tiled over 5k..1.28M time steps, mel and waveform vs the oracle"""
+    from oracle import dict_tts_ref as ref
+    from oracle import hifigan_ref as href
+    st = synth.biaobei_struct()
+    ids = [w for s in st["sentences"] for w in s][:1000]
+    batch = synth.make_batch([ids], gc.SEED)
+    m2w = synth.teacher_mel2word(batch["word_tokens"], 5, 5)
+    assert batch["word_tokens"].shape[1] == 1002 and m2w.shape[1] == 5010
+    b = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], mel2word=T(m2w), z_p=lambda B, T4: T(synth.noise(21, B, T4)))
+    T_mel = want["mel_out"].shape[1]
+    assert T_mel == 5012
+    got = _run(acoustic, batch, z=T(synth.noise(21, 1, T_mel // 4)), mel2word=T(m2w))
+    assert (got["word_encoder_out"].cpu() - want["word_encoder_out"]).abs().max() <= 2e-4
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    mel = want["mel_out"][0].numpy()
+    wav = voc_bf16.spec2wav(mel)
+    wref = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel).numpy()
+    assert wav.shape == wref.shape == (5012 * 256,)
+    assert abs(rms(wav) - rms(wref)) <= 1e-4 and rms(wav - wref) <= 0.02 * rms(wref)
+
+
+def test_config5_dictionary_stress_mixed_lengths(acoustic, oracle_sd):
+    """BASELINE.json configs[4] (one GPU's share): B=32 mixed-length utterances (6..60 chars) drawn from the whole
+    dictionary structure with heteronyms over-sampled x5, word ids up to word_size=8000, every char forced to a sense"""
+    from oracle import dict_tts_ref as ref
+    st = synth.biaobei_struct()
+    rng = np.random.default_rng(5)
+    ids = np.array(sorted(st["entries"].keys()))
+    wts = np.array([5.0 if len(st["entries"][i]) > 1 else 1.0 for i in ids])
+    wts /= wts.sum()
+    sents = [rng.choice(ids, size=int(rng.integers(6, 61)), p=wts).tolist() for _ in range(32)]
+    batch = synth.make_batch(sents, gc.SEED, pron_every=3)
+    batch["word_tokens"][batch["word_tokens"] == synth.BOS_ID] = 7999          # highest row of the 8000-word table
+    b = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], z_p=lambda B, T4: T(synth.noise(31, B, T4)))
+    T_mel = want["mel_out"].shape[1]
+    got = _run(acoustic, batch, z=T(synth.noise(31, 32, T_mel // 4)))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"])
+    assert (got["pron_attn"].cpu() - want["pron_attn"]).abs().max() <= 1e-5
+    assert (got["dict_attn"].cpu() - want["dict_attn"]).abs().max() <= 1e-5
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    from dict_tts_amd.model import decode_pinyin_ids
+    for u in range(32):
+        assert decode_pinyin_ids(got["pron_attn"][u], batch["pinyin"][u]) == ref.decode_pinyin(want["pron_attn"][u], b["pinyin"][u])
