@@ -61,80 +61,120 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     if (live)
         for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
             // ---- stage X[in0 .. in0+rows) x [ci0, ci0+CK) into LDS (pre-activation, zero padding, conversion)
-            for (int idx = tid; idx < rows * (CK / 4); idx += 256) {
-                const int r = idx / (CK / 4), c4 = idx % (CK / 4);
-                const int t = in0 + r, ci = ci0 + c4 * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (t >= 0 && t < in_len && ci < p.C_in) {
-                    v = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
-                    if (p.pre_act) {
+            {   // batches of U independent 16 B loads in flight per thread, then conversion + LDS writes
+                constexpr int U = 4, PIECES = CK / 4;
+                const int total = rows * PIECES;
+                for (int base = tid; base < total; base += 256 * U) {
+                    f32x4 vv[U];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = base + u * 256;
+                        const int r = idx / PIECES, c4 = idx % PIECES;
+                        const int t = in0 + r, ci = ci0 + c4 * 4;
+                        vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (idx < total && t >= 0 && t < in_len && ci < p.C_in) vv[u] = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
                     }
-                }
-                if constexpr (ENGINE == ENG_F32) {
-                    *(f32x4*)(smem + r * PITCH + c4 * 16) = v;
-                } else {
-                    unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
-                    uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                    *(uint2*)(smem + r * PITCH + c4 * 8) = hi;
-                    if constexpr (ENGINE == ENG_BF16X3) {
-                        unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
-                        unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
-                        *(uint2*)(lds_lo + r * PITCH + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = base + u * 256;
+                        if (idx >= total) continue;
+                        const int r = idx / PIECES, c4 = idx % PIECES;
+                        f32x4 v = vv[u];
+                        if (p.pre_act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+                        }
+                        if constexpr (ENGINE == ENG_F32) {
+                            *(f32x4*)(smem + r * PITCH + c4 * 16) = v;
+                        } else {
+                            unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+                            *(uint2*)(smem + r * PITCH + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                            if constexpr (ENGINE == ENG_BF16X3) {
+                                unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
+                                unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
+                                *(uint2*)(lds_lo + r * PITCH + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                            }
+                        }
                     }
                 }
             }
             __syncthreads();
-            // ---- contraction over taps and k-groups of this chunk
-            const int g0 = ci0 / KG;
-            for (int tap = 0; tap < p.K; ++tap) {
-                const uint4* wh = (const uint4*)p.w_hi + ((size_t)(tap * NG + g0) * NCT) * 64 + lane;
-                const uint4* wl = (const uint4*)p.w_lo + ((size_t)(tap * NG + g0) * NCT) * 64 + lane;
+            // ---- contraction over taps and k-groups of this chunk.  Steps s = tap * NKG + kg; weight fragments
+            // run PF steps ahead in a register ring, activation fragments one step ahead (double buffer); the
+            // sched_barriers keep those prefetches above the MFMAs of the current step.
+            {
+                constexpr int R = NKG < 4 ? NKG : 4, PF = R - 1;
+                const int g0 = ci0 / KG;
+                const int S = p.K * NKG;
+                const size_t tap_stride = (size_t)NG * NCT * 64, kg_stride = (size_t)NCT * 64;
+                const uint4* wh = (const uint4*)p.w_hi + (size_t)g0 * NCT * 64 + lane;
+                const uint4* wl = (const uint4*)p.w_lo + (size_t)g0 * NCT * 64 + lane;
+                int ctc[NT];
+                bool ctv[NT];
 #pragma unroll
-                for (int kg = 0; kg < NKG; ++kg) {
-                    uint4 bh[NT], bl[NT];
+                for (int n = 0; n < NT; ++n) {
+                    ctv[n] = ct0 + n < NCT;
+                    ctc[n] = ctv[n] ? ct0 + n : NCT - 1;
+                }
+                auto load_w = [&](uint4 (&dh)[NT], uint4 (&dl)[NT], int s) {
+                    const int sc = s < S ? s : S - 1;
+                    const size_t off = (size_t)(sc / NKG) * tap_stride + (size_t)(sc % NKG) * kg_stride;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const int ct = ct0 + n;
-                        if (ct < NCT) {
-                            bh[n] = wh[((size_t)kg * NCT + ct) * 64];
-                            if constexpr (ENGINE == ENG_BF16X3) bl[n] = wl[((size_t)kg * NCT + ct) * 64];
-                        } else {
-                            bh[n] = make_uint4(0, 0, 0, 0);
-                            bl[n] = make_uint4(0, 0, 0, 0);
-                        }
+                        dh[n] = wh[off + (size_t)ctc[n] * 64];
+                        if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[off + (size_t)ctc[n] * 64];
                     }
-                    uint4 ah[MT], al[MT];
+                };
+                const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * PITCH + (lane >> 5) * (KG / 2) * ES;
+                auto load_x = [&](uint4 (&dh)[MT], uint4 (&dl)[MT], int s) {
+                    const int sc = s < S ? s : S - 1;
+                    const int off = abase + (sc / NKG) * p.dil * PITCH + (sc % NKG) * KG * ES;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        const int i = (wt * MT + m) * 32 + (lane & 31);
-                        const int off = (i * p.stride + tap * p.dil) * PITCH + (kg * KG + (lane >> 5) * (KG / 2)) * ES;
-                        ah[m] = *(const uint4*)(smem + off);
-                        if constexpr (ENGINE == ENG_BF16X3) al[m] = *(const uint4*)(lds_lo + off);
+                        dh[m] = *(const uint4*)(smem + off + m * 32 * p.stride * PITCH);
+                        if constexpr (ENGINE == ENG_BF16X3) dl[m] = *(const uint4*)(lds_lo + off + m * 32 * p.stride * PITCH);
                     }
+                };
+                uint4 rh[R][NT], rl[R][NT], xh[2][MT], xl[2][MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                for (int s = 0; s < PF; ++s) load_w(rh[s], rl[s], s);
+                load_x(xh[0], xl[0], 0);
+                for (int tap = 0; tap < p.K; ++tap) {
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            if constexpr (ENGINE == ENG_F32) {
-                                const f32x4 a = *(const f32x4*)&ah[m];
-                                const f32x4 w = *(const f32x4*)&bh[n];
+                    for (int kg = 0; kg < NKG; ++kg) {
+                        const int s = tap * NKG + kg;
+                        load_w(rh[(kg + PF) % R], rl[(kg + PF) % R], s + PF);
+                        load_x(xh[(kg + 1) & 1], xl[(kg + 1) & 1], s + 1);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int s = 0; s < 4; ++s)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc[m][n], 0, 0, 0);
-                            } else {
-                                const bf16x8 a = *(const bf16x8*)&ah[m];
-                                const bf16x8 w = *(const bf16x8*)&bh[n];
-                                if constexpr (ENGINE == ENG_BF16X3) {
-                                    const bf16x8 a2 = *(const bf16x8*)&al[m];
-                                    const bf16x8 w2 = *(const bf16x8*)&bl[n];
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w, acc[m][n], 0, 0, 0);
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                uint4 bh = rh[kg % R][n], bl = rl[kg % R][n];
+                                if (!ctv[n]) {
+                                    bh = make_uint4(0, 0, 0, 0);
+                                    bl = make_uint4(0, 0, 0, 0);
                                 }
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[m][n], 0, 0, 0);
+                                if constexpr (ENGINE == ENG_F32) {
+                                    const f32x4 a = *(const f32x4*)&xh[kg & 1][m];
+                                    const f32x4 w = *(const f32x4*)&bh;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], w[q], acc[m][n], 0, 0, 0);
+                                } else {
+                                    const bf16x8 a = *(const bf16x8*)&xh[kg & 1][m];
+                                    const bf16x8 w = *(const bf16x8*)&bh;
+                                    if constexpr (ENGINE == ENG_BF16X3) {
+                                        const bf16x8 a2 = *(const bf16x8*)&xl[kg & 1][m];
+                                        const bf16x8 w2 = *(const bf16x8*)&bl;
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w, acc[m][n], 0, 0, 0);
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, acc[m][n], 0, 0, 0);
+                                    }
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[m][n], 0, 0, 0);
+                                }
                             }
-                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             __syncthreads();
