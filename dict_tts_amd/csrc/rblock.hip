@@ -26,14 +26,18 @@ __device__ __forceinline__ unsigned rf2bf(float f) {  // round-to-nearest-even f
 constexpr int RB_GUARD = 32;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap of dilation 5)
 
 // acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]
-template <int MT, int NT, int NKG, int PITCH>
-__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], const char* act, int xrow0, const uint4* w, int S, int dilP,
-                                            int kg_stride) {
-    uint4 ring[4][NT];
+// first PF = 3 weight fragments of a convolution (issued early: before the barriers / activation writes that precede it)
+template <int NT>
+__device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w, int kg_stride) {
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kg_stride + n * 64];
+}
+
+template <int MT, int NT, int NKG, int PITCH>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
+                                            int S, int dilP, int kg_stride) {
     uint4 xa[2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
@@ -132,8 +136,15 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         }
     }
 
-    // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance
-    auto write_act = [&](const f32x16 (&v)[MT][NT], const float* bias) {
+    // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance.
+    // bias: this lane's 4 channel quads per co-tile, loaded into registers BEFORE the contraction it follows.
+    auto load_bias = [&](f32x4 (&bb)[NT][4], const float* bias) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(bias + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
+    };
+    auto write_act = [&](const f32x16 (&v)[MT][NT], const f32x4 (&bb)[NT][4], bool use_bias) {
         if (p.dbg & 8) return;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -145,13 +156,11 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-                    if (bias) bb = *(const f32x4*)(bias + co);
                     unsigned h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float a = v[m][n][4 * q + e] + bb[e];
-                        a = a > 0.f ? a : a * 0.1f;
+                        float a = v[m][n][4 * q + e] + (use_bias ? bb[n][q][e] : 0.f);
+                        a = fmaxf(a, a * 0.1f);  // leaky_relu, slope 0.1 < 1
                         h[e] = inb ? rf2bf(a) : 0u;
                     }
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
@@ -159,12 +168,17 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         }
     };
 
-    write_act(xr, nullptr);
-    __syncthreads();
-
     const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const int kg_stride = (C / 32) * 64;
     const int S = (p.dbg & 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
+    const size_t wlane = (size_t)(wc * NT) * 64 + lane;
+    uint4 ring[4][NT];
+    f32x4 bb[NT][4];   // one live bias set: b1 while conv1 runs, b2 while conv2 runs
+    rb_preload<NT>(ring, p.w1[0] + wlane, kg_stride);   // in flight during the first activation write
+    write_act(xr, bb, false);
+    load_bias(bb, p.b1[0]);
+    __syncthreads();
+
     f32x16 acc[MT][NT];
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -175,10 +189,11 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         const int d = p.dil[it];
-        rb_contract<MT, NT, NKG, PITCH>(acc, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + (size_t)(wc * NT) * 64 + lane, S,
-                                        d * PITCH, kg_stride);
+        rb_contract<MT, NT, NKG, PITCH>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride);
+        rb_preload<NT>(ring, p.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
-        write_act(acc, p.b1[it]);      // xt (bf16, activated) overwrites it
+        write_act(acc, bb, true);      // xt (bf16, activated) overwrites it
+        load_bias(bb, p.b2[it]);       // lands while conv2 runs
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -186,21 +201,20 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        rb_contract<MT, NT, NKG, PITCH>(acc, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + (size_t)(wc * NT) * 64 + lane, S, PITCH,
-                                        kg_stride);
+        rb_contract<MT, NT, NKG, PITCH>(acc, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
+        if (it < 2) rb_preload<NT>(ring, p.w1[it + 1] + wlane, kg_stride);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bb = *(const f32x4*)(p.b2[it] + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += acc[m][n][4 * q + e] + bb[e];  // x = xt + x
-            }
+                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += acc[m][n][4 * q + e] + bb[n][q][e];  // x = xt + x
         __syncthreads();               // every wave is done reading xt
         if (it < 2) {
-            write_act(xr, nullptr);
+            write_act(xr, bb, false);
+            load_bias(bb, p.b1[it + 1]);
             __syncthreads();
         }
     }

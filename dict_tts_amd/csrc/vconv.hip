@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     const unsigned short* xb = p.x + (long long)b * p.T * p.ldx;
     const int xoff = ((wt * MT) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;  // B-operand base of this lane
 
+    // weight-fragment ring; the first PF fragments of a chunk are requested BEFORE its activation tile is staged,
+    // so their L2 latency overlaps the staging loads
+    const size_t tap_stride = (size_t)NG * NCT * 64, kg_stride = (size_t)NCT * 64;
+    uint4 ring[R][NT];
+    auto preload = [&](int ci0) {
+        const uint4* wc0 = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int sc = s < S ? s : S - 1;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ring[s % R][n] = wc0[(sc / NKG) * tap_stride + (sc % NKG) * kg_stride + n * 64];
+        }
+    };
+    preload(0);
     for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
         if (ci0) __syncthreads();
         if (!(p.dbg & 4)) {   // stage the activation tile: batches of U independent 16 B loads in flight per thread, then the LDS writes
@@ -83,15 +97,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
         }
         __syncthreads();
         const uint4* wchunk = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;  // (tap 0, first k-group of the chunk)
-        const size_t tap_stride = (size_t)NG * NCT * 64, kg_stride = (size_t)NCT * 64;
-        uint4 ring[R][NT];
-#pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int sc = s < S ? s : S - 1;
-            const int tp = sc / NKG, kp = sc % NKG;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) ring[s % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
-        }
         // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s
         uint4 xa[2][MT];
 #pragma unroll
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (ci0 + CK < p.C_in_pad) preload(ci0 + CK);
     }
 
     if (p.dbg & 2) {

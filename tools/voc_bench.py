@@ -40,3 +40,12 @@ ms, n = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
 frames = int(lens.sum())
 print(f"frames {frames}  wall {dt * 1e3:.2f} ms/forward  conv-kernel {ms / a.iters:.2f} ms/forward  "
       f"{614105088 * frames / (ms / a.iters * 1e-3) / 1e12:.1f} TFLOP/s  ({frames / dt:.0f} frames/s vocoder-only)")
+if os.environ.get("DTTS_CALIB"):
+    # known-byte-count kernels for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md §HBM)
+    big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")   # 256 MiB
+    big.fill_(1.0)
+    torch.cuda.synchronize()
+    c = big.clone()                                             # reads 256 MiB, writes 256 MiB
+    torch.cuda.synchronize()
+    s = big.sum()                                               # reads 256 MiB
+    torch.cuda.synchronize()
