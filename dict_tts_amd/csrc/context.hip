@@ -508,7 +508,8 @@ int build_vocoder(dtts_ctx* h) {
                 if (!w || bias.empty()) { ok = false; break; }
                 const float* pw = w->f.data();
                 PackedConv& L = which ? h->rbf2[i][mth] : h->rbf1[i][mth];
-                ok = pack_conv(h, L, ENG_BF16, ch, ch, kp,
+                const int slack = ch >= 64 ? 1 : 2;   // >= 4 zero k-steps behind the last tap: the weight prefetch never clamps
+                ok = pack_conv(h, L, ENG_BF16, ch, ch, kp + slack,
                                [=](int co, int ci, int tap) { return tap < k ? pw[((size_t)co * ch + ci) * k + tap] : 0.f; }, bias,
                                which ? 1 : c.resblock_dilation_sizes[j][mth], 1, 0);
                 L.K = k;

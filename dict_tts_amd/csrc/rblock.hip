@@ -23,7 +23,7 @@ __device__ __forceinline__ unsigned rf2bf(float f) {  // round-to-nearest-even f
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
-constexpr int RB_GUARD = 32;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap of dilation 5)
+constexpr int RB_GUARD = 40;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap + one prefetched tap, dilation 5)
 
 // acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]
 // first PF = 3 weight fragments of a convolution (issued early: before the barriers / activation writes that precede it)
@@ -35,28 +35,41 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
         for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kg_stride + n * 64];
 }
 
+// acc += W * act over all taps.  Steps are processed 4 at a time (= TU taps); inside a group every LDS / global
+// offset is a compile-time immediate off two VGPR bases that advance once per group, so the loop body is MFMAs,
+// ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
+// activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
+// of guard rows, so the prefetches past the last step need no clamping.
 template <int MT, int NT, int NKG, int PITCH>
 __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
-                                            int S, int dilP, int kg_stride) {
+                                            int S, int dilP, int kg_stride_unused) {
+    constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
+    constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
+    constexpr int KGS = (NKG / 2) * 64;               // uint4 elements between consecutive steps (= NCT * 64, NCT = NKG / 2)
     uint4 xa[2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
+    const uint4* wpf = w + 3 * KGS;                   // prefetch pointer, 3 steps ahead
+    int xb = xrow0;                                   // LDS byte offset of (tap of this group, kg 0)
+    int g = 0;
     for (int s0 = 0; s0 < S; s0 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int s = s0 + u;
-            {
-                const int sp = (s + 3 < S) ? s + 3 : S - 1;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = w[(size_t)sp * kg_stride + n * 64];
-            }
-            {
-                const int sn = (s + 1 < S) ? s + 1 : S - 1;
-                const int off = xrow0 + (sn / NKG) * dilP + (sn % NKG) * 32;
+            for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
+            {   // activation fragments of step u+1
+                int off;
+                if constexpr (NKG >= 4) {
+                    const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
+                    off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
+                } else {
+                    const int un = u + 1;                        // step within the group of TU taps
+                    off = xb + (un / NKG) * dilP + (un % NKG) * 32;
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads / weight load ABOVE this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -64,6 +77,15 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
                                                                         acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        wpf += 4 * KGS;
+        if constexpr (NKG >= 4) {
+            if (++g == GPT) {
+                g = 0;
+                xb += dilP;
+            }
+        } else {
+            xb += TU * dilP;
         }
     }
 }
@@ -144,13 +166,14 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
             for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(bias + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     };
-    auto write_act = [&](const f32x16 (&v)[MT][NT], const f32x4 (&bb)[NT][4], bool use_bias) {
+    const bool all_inb = base_t >= 0 && base_t + W <= len;   // block-uniform: no row of the tile needs masking
+    auto write_act = [&](const f32x16 (&v)[MT][NT]) {
         if (p.dbg & 8) return;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = (wt * MT + m) * 32 + (lane & 31);
             const int t = base_t + row;
-            const bool inb = t >= 0 && t < len;
+            const bool inb = all_inb || (t >= 0 && t < len);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -159,11 +182,12 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
                     unsigned h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float a = v[m][n][4 * q + e] + (use_bias ? bb[n][q][e] : 0.f);
-                        a = fmaxf(a, a * 0.1f);  // leaky_relu, slope 0.1 < 1
-                        h[e] = inb ? rf2bf(a) : 0u;
+                        const float a = v[m][n][4 * q + e];
+                        h[e] = rf2bf(fmaxf(a, a * 0.1f));  // leaky_relu, slope 0.1 < 1
                     }
-                    *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    if (!inb) pk = make_uint2(0, 0);
+                    *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
         }
     };
@@ -173,48 +197,46 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
     const int S = (p.dbg & 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
     const size_t wlane = (size_t)(wc * NT) * 64 + lane;
     uint4 ring[4][NT];
-    f32x4 bb[NT][4];   // one live bias set: b1 while conv1 runs, b2 while conv2 runs
+    f32x4 bb[NT][4];   // one live bias set
     rb_preload<NT>(ring, p.w1[0] + wlane, kg_stride);   // in flight during the first activation write
-    write_act(xr, bb, false);
     load_bias(bb, p.b1[0]);
+    write_act(xr);
     __syncthreads();
 
     f32x16 acc[MT][NT];
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
+        // conv1: the accumulator starts at the bias (no separate bias pass)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][n][4 * q + e] = bb[n][q][e];
+        load_bias(bb, p.b2[it]);       // lands while conv1 runs
         const int d = p.dil[it];
         rb_contract<MT, NT, NKG, PITCH>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride);
         rb_preload<NT>(ring, p.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
-        write_act(acc, bb, true);      // xt (bf16, activated) overwrites it
-        load_bias(bb, p.b2[it]);       // lands while conv2 runs
+        write_act(acc);                // xt (bf16, activated) overwrites it
         __syncthreads();
+        // conv2 accumulates straight into the residual registers: x = x + b2 + W2 * xt
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        rb_contract<MT, NT, NKG, PITCH>(acc, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
+        if (it < 2) load_bias(bb, p.b1[it + 1]);
+        rb_contract<MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, p.w1[it + 1] + wlane, kg_stride);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += acc[m][n][4 * q + e] + bb[n][q][e];  // x = xt + x
         __syncthreads();               // every wave is done reading xt
         if (it < 2) {
-            write_act(xr, bb, false);
-            load_bias(bb, p.b1[it + 1]);
+            write_act(xr);
             __syncthreads();
         }
     }
