@@ -192,7 +192,7 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
     L.flops_per_row = flops_per_row >= 0 ? flops_per_row : 2.0 * C_out * C_in * K;
     const int KG = engine == ENG_F32 ? 8 : 16, E = KG / 2;
     const int NG = L.C_in_pad / KG, NCT = L.C_out_pad / 32;
-    const size_t n = (size_t)K * L.C_in_pad * L.C_out_pad;
+    const size_t n = (size_t)K * L.C_in_pad * L.C_out_pad + (size_t)8 * 16 * L.C_out_pad;  // + 8 zero k-steps of slack (prefetch past the end)
     std::vector<float> wf;
     std::vector<uint16_t> whi, wlo;
     if (engine == ENG_F32) wf.assign(n, 0.f);

@@ -43,9 +43,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     const int ct0 = blockIdx.y * (CO_T / 32) + wc * NT;
     const int NCT = p.C_out_pad >> 5;
     const int NG = p.C_in_pad >> 4;
-    const int rows = TT + (p.K - 1) * p.dil;
+    const int rows = TT + (p.K - 1) * p.dil;   // + one spare tap of rows is allocated (never staged, only prefetched)
     const int in0 = t0 - p.pad;
-    const int S = p.K * NKG;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -58,17 +57,22 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     const unsigned short* xb = p.x + (long long)b * p.T * p.ldx;
     const int xoff = ((wt * MT) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;  // B-operand base of this lane
 
-    // weight-fragment ring; the first PF fragments of a chunk are requested BEFORE its activation tile is staged,
-    // so their L2 latency overlaps the staging loads
-    const size_t tap_stride = (size_t)NG * NCT * 64, kg_stride = (size_t)NCT * 64;
+    // weight-fragment ring.  One running pointer walks the packed weights PF steps ahead of the MFMAs: +kg_stride per
+    // step, +tap_jump when the prefetched step wraps to the next tap, so the loop body carries two 64-bit adds instead
+    // of div/mod/multiply address arithmetic.  The first PF fragments of a chunk are requested BEFORE its activation
+    // tile is staged (L2 latency overlaps the staging loads); the packed buffer has PF+1 steps of slack at its end.
+    const size_t kg_stride = (size_t)NCT * 64;
+    const size_t tap_jump = (size_t)NG * NCT * 64 - (size_t)NKG * kg_stride;
     uint4 ring[R][NT];
+    const uint4* wpf = p.w + (size_t)ct0 * 64 + lane;
     auto preload = [&](int ci0) {
-        const uint4* wc0 = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;
+        wpf = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
-            const int sc = s < S ? s : S - 1;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) ring[s % R][n] = wc0[(sc / NKG) * tap_stride + (sc % NKG) * kg_stride + n * 64];
+            for (int n = 0; n < NT; ++n) ring[s % R][n] = wpf[n * 64];
+            wpf += kg_stride;
+            if ((s + 1) % NKG == 0) wpf += tap_jump;
         }
     };
     preload(0);
@@ -96,26 +100,22 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
             }
         }
         __syncthreads();
-        const uint4* wchunk = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;  // (tap 0, first k-group of the chunk)
         // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s
         uint4 xa[2][MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(smem + xoff + m * 32 * PITCH);
-        for (int tap = 0; tap < ((p.dbg & 1) ? 0 : p.K); ++tap) {
-            const int arow = xoff + tap * p.dil * PITCH;
-            const int arow_next = xoff + (tap + 1 < p.K ? tap + 1 : tap) * p.dil * PITCH;
+        const int ntap = (p.dbg & 1) ? 0 : p.K;
+        const int dilP = p.dil * PITCH;
+        int arow = xoff;
+        for (int tap = 0; tap < ntap; ++tap) {
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
-                {   // weight prefetch, PF steps ahead (clamped at the end: branch-free body)
-                    int sp = tap * NKG + kg + PF;
-                    sp = sp < S ? sp : S - 1;
-                    const int tp = sp / NKG, kp = sp % NKG;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        ring[(kg + PF) % R][n] = wchunk[tp * tap_stride + kp * kg_stride + n * 64];
-                }
+                for (int n = 0; n < NT; ++n) ring[(kg + PF) % R][n] = wpf[n * 64];   // step s + PF
+                wpf += kg_stride;
+                if ((kg + PF + 1) % NKG == 0) wpf += tap_jump;
                 {
-                    const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow_next;
+                    const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow + dilP;   // LDS tile has one spare tap of rows
 #pragma unroll
                     for (int m = 0; m < MT; ++m) xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
                 }
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
                                                                             *(const bf16x8*)&xa[kg & 1][m], acc[m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            arow += dilP;
         }
         if (ci0 + CK < p.C_in_pad) preload(ci0 + CK);
     }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
 template <int MT, int NT, int WT, int WC, int CK>
 static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
     constexpr int PITCH = CK * 2 + 16, TT = 32 * MT * WT, CO_T = 32 * NT * WC;
-    const int rows = TT + (p.K - 1) * p.dil;
+    const int rows = TT + p.K * p.dil;   // incl. one spare tap for the activation-fragment prefetch past the last step
     size_t lds = (size_t)rows * PITCH;
     const size_t ep = (size_t)WT * 32 * (CO_T * 4 + 16);
     if (ep > lds) lds = ep;
