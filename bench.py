@@ -205,6 +205,16 @@ def main():
         value = frames_total / elapsed
         samples = value * voc.hop
         achieved = FLOP_PER_FRAME_VOCODER * frames_rank / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # HBM bytes of the same kernel family: PMC counters cannot be read from inside the process, so the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE result of this command (profiles/r01_c_pmc_traffic.json, corrected
+        # as MI355X_MICROARCH.md prescribes) is scaled by this run's frame count; null if the file is absent
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+        if args.precision == "bf16" and os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_bytes_per_mel_frame"] * (frames_rank / max(args.steps, 1)) / max(conv_launches / max(args.steps, 1), 1)
+            traffic_src = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch, avg)"
         out = {
             "metric": "mel-frames/sec, end-to-end text->mel->wav (audio-samples/sec = 256x; RTF reported alongside)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,8 +228,9 @@ def main():
                        "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision},
             "audio_samples_per_sec": samples, "rtf": 22050.0 / samples,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "dtts::conv1d_cl_kernel<bf16> (all HifiGAN layers)", "launches": conv_launches,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "dtts::vconv_kernel<*> + dtts::rblock_kernel<*> (every HifiGAN convolution; 48 launches/step)",
+                         "launches": conv_launches,
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "kernel_ms_per_step": conv_ms / max(args.steps, 1),
                          "algorithmic_flop_per_mel_frame": FLOP_PER_FRAME_VOCODER},
         }
