@@ -19,6 +19,7 @@
 #include "ops.h"
 #include "vconv.h"
 #include "rblock.h"
+#include "vpair.h"
 
 using namespace dtts;
 
@@ -693,12 +694,13 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
         }
     }
     const int melC = h->conv_pre.C_in_pad;
-    HIPCHK(h->a_voc.reserve(max_elems * (3 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
+    HIPCHK(h->a_voc.reserve(max_elems * (4 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
                             (size_t)(nup + 2) * B * sizeof(int) + (64 << 10)));
     Arena& A = h->a_voc;
     float* Xf = A.alloc<float>(max_elems);
     float* Rf = A.alloc<float>(max_elems);
     float* Sf = A.alloc<float>(max_elems);
+    float* Rg = A.alloc<float>(max_elems);   // second ping-pong buffer of the fused-iteration path (vpair.hip)
     bf* Xa = A.alloc<bf>(max_elems);
     bf* Ra = A.alloc<bf>(max_elems);
     bf* Ta = A.alloc<bf>(max_elems);
@@ -706,7 +708,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
     bf* melb = A.alloc<bf>((size_t)B * T * melC);
     int* lensS = A.alloc<int>((size_t)(nup + 1) * B);
     int* mult_d = A.alloc<int>(nup + 1);
-    if (!Xf || !Rf || !Sf || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
     {
         int mult[9];
         mult[0] = 1;
@@ -775,6 +777,38 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
                 LAUNCH(rblock_launch(rp, ch, s));
+                continue;
+            }
+            if (fuse && vpair_supported(ch, c1[0].K, c1[0].dil) && vpair_supported(ch, c1[2].K, c1[2].dil) && c1[0].C_in_pad == ch) {
+                // one kernel per ResBlock iteration (vpair.hip): fp32 stream in, fp32 stream out
+                const float* xin = Xf;
+                for (int mth = 0; mth < 3; ++mth) {
+                    VPairParams vp;
+                    memset(&vp, 0, sizeof vp);
+                    vp.x = xin;
+                    vp.w1 = (const uint4*)c1[mth].w_hi;
+                    vp.w2 = (const uint4*)c2[mth].w_hi;
+                    vp.b1 = c1[mth].bias;
+                    vp.b2 = c2[mth].bias;
+                    vp.lens = lout;
+                    vp.B = B;
+                    vp.T = Tcur;
+                    vp.K = c1[mth].K;
+                    vp.dil = c1[mth].dil;
+                    vp.div = (float)nk;
+                    vp.slope = last_stage ? 0.01f : 0.1f;
+                    if (mth < 2) {
+                        vp.y = mth == 0 ? Rf : Rg;
+                        vp.mode = 1;
+                    } else {
+                        vp.y = Sf;
+                        vp.mode = j == 0 ? 1 : (j == nk - 1 ? 3 : 2);
+                        vp.ya = Sa;
+                    }
+                    xin = vp.y;
+                    Timed tm(h, TV, s);
+                    LAUNCH(vpair_launch(vp, ch, s));
+                }
                 continue;
             }
             for (int mth = 0; mth < 3; ++mth) {

@@ -1,0 +1,86 @@
+// Shared device helpers of the fused HifiGAN kernels (rblock.hip, vpair.hip): bf16 conversion, the weight-fragment
+// ring preload and the static-offset MFMA contraction loop over an LDS activation tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dtts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned rf2bf(float f) {  // round-to-nearest-even fp32 -> bf16 bits (hardware convert)
+    const __bf16 h = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+
+constexpr int RB_GUARD = 40;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap + one prefetched tap, dilation 5)
+
+// acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]
+// first PF = 3 weight fragments of a convolution (issued early: before the barriers / activation writes that precede it)
+template <int NT>
+__device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w, int kg_stride) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kg_stride + n * 64];
+}
+
+// acc += W * act over all taps.  Steps are processed 4 at a time (= TU taps); inside a group every LDS / global
+// offset is a compile-time immediate off two VGPR bases that advance once per group, so the loop body is MFMAs,
+// ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
+// activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
+// of guard rows, so the prefetches past the last step need no clamping.
+template <int MT, int NT, int NKG, int PITCH>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
+                                            int S, int dilP, int kg_stride_unused) {
+    constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
+    constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
+    constexpr int KGS = (NKG / 2) * 64;               // uint4 elements between consecutive steps (= NCT * 64, NCT = NKG / 2)
+    uint4 xa[2][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
+    const uint4* wpf = w + 3 * KGS;                   // prefetch pointer, 3 steps ahead
+    int xb = xrow0;                                   // LDS byte offset of (tap of this group, kg 0)
+    int g = 0;
+    for (int s0 = 0; s0 < S; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
+            {   // activation fragments of step u+1
+                int off;
+                if constexpr (NKG >= 4) {
+                    const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
+                    off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
+                } else {
+                    const int un = u + 1;                        // step within the group of TU taps
+                    off = xb + (un / NKG) * dilP + (un % NKG) * 32;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
+                                                                        acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wpf += 4 * KGS;
+        if constexpr (NKG >= 4) {
+            if (++g == GPT) {
+                g = 0;
+                xb += dilP;
+            }
+        } else {
+            xb += TU * dilP;
+        }
+    }
+}
+
+
+} // namespace dtts

@@ -1,0 +1,25 @@
+// One fused ResBlock1 iteration for the C = 128 HifiGAN stage: see vpair.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dtts {
+
+struct VPairParams {
+    const float* x;       // fp32 residual stream in, [B][T][C]; must not alias y (neighbouring tiles read halos)
+    float* y;             // mode 1: y = x';  mode 2: y += x';  mode 3: y = (y + x') / div and ya = bf16 leaky_relu(y, slope)
+    unsigned short* ya;
+    const uint4* w1;      // convs1[m] (dilated) / convs2[m] packed bf16 weights, single C_in chunk
+    const uint4* w2;
+    const float* b1;
+    const float* b2;
+    const int* lens;      // [B] valid rows
+    int B, T, K, dil;
+    int mode;
+    float div, slope;
+};
+
+bool vpair_supported(int C, int K, int dil);
+hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream);
+
+} // namespace dtts

@@ -1,0 +1,191 @@
+// One ResBlock1 iteration  x <- x + c2(leaky_relu(c1(leaky_relu(x))))  (modules/hifigan/hifigan.py:51-58) in ONE
+// kernel, for the C = 128 stage (bf16 MFMA).  Per-convolution, that stage is HBM-bound: 2.2 KB per row and iteration
+// (bf16 copies in/out, the bf16 xt round trip, fp32 residual in/out).  Here a workgroup
+//   * reads the fp32 stream once (tile + halo of d(k-1)/2 + (k-1)/2 rows), applies leaky_relu + bf16 rounding while
+//     staging it into LDS (the same rounding point as everywhere else),
+//   * runs c1 for 128 rows of xt, barriers, overwrites the LDS tile with bf16(leaky_relu(xt)) (zero outside the
+//     utterance = the reference's zero padding), runs c2 for 128 - (k-1) valid output rows,
+//   * re-reads the centre rows of x for the residual (L2-hot: this block staged them a moment ago) in the coalesced
+//     epilogue and writes only the fp32 result (or accumulates into the stage sum xs for the last iteration).
+// HBM bytes per row and iteration: ~0.8 KB in + 0.5 KB out.  4 waves over output channels, 3 workgroups per CU.
+#include "vpair.h"
+
+#include "rb_common.h"
+
+namespace dtts {
+
+template <int C>
+__global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, NT = 1, TT = 128;
+    constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
+    constexpr int EP = C * 4 + 16, F4 = C / 4;
+    static_assert(NCT == 4, "one co-tile per wave");
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int b = blockIdx.y;
+    const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
+    const int TTe = TT - 2 * h2;             // valid output rows per workgroup
+    const int t0 = blockIdx.x * TTe;
+    const int len = p.lens ? p.lens[b] : p.T;
+    if (t0 >= len) return;
+    const long long brow = (long long)b * p.T;
+    const int S = p.K * NKG;
+
+    uint4 ring[4][NT];
+    const size_t wlane = (size_t)wc * 64 + lane;
+    rb_preload<NT>(ring, p.w1 + wlane, NCT * 64);   // c1's first weights fly while the tile is staged
+
+    // ---- stage bf16(leaky_relu(x)) for rows [t0 - h2 - h1, t0 - h2 + TT + h1) ; zero outside the utterance
+    const int a0 = t0 - h2 - h1;
+    const int arows = TT + 2 * h1;
+    {
+        constexpr int U = 4;
+        const int total = arows * F4;
+        for (int base = tid; base < total; base += 256 * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const int r = idx / F4, c4 = idx % F4;
+                const int t = a0 + r;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < total && t >= 0 && t < len) v[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                if (idx >= total) continue;
+                const int r = idx / F4, c4 = idx % F4;
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = rf2bf(fmaxf(v[u][e], v[u][e] * 0.1f));
+                *(uint2*)(smem + r * PITCH + c4 * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+    // this lane's bias quads
+    f32x4 bb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b1 + wc * 32 + 8 * q + 4 * (lane >> 5));
+    __syncthreads();
+
+    // ---- c1: xt rows r = 0..127  <->  global t0 - h2 + r ; reads staged rows r + tap * d
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][0][4 * q + e] = bb[q][e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b2 + wc * 32 + 8 * q + 4 * (lane >> 5));
+    const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
+    rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0);
+    rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
+    __syncthreads();   // every wave is done reading the x tile
+    // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = m * 32 + (lane & 31);
+        const int t = t0 - h2 + r;
+        const bool inb = t >= 0 && t < len;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = acc[m][0][4 * q + e];
+                h[e] = rf2bf(fmaxf(a, a * 0.1f));
+            }
+            uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            if (!inb) pk = make_uint2(0, 0);
+            *(uint2*)(smem + r * PITCH + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
+        }
+    }
+    __syncthreads();
+    // ---- c2: output rows o = 0..127 <-> global t0 + o (valid for o < TTe) ; reads xt rows o + tap
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][0][4 * q + e] = bb[q][e];
+    rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0);
+    __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
+
+    // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode
+    constexpr int PER = 32 * F4 / 256;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[m][0][4 * q + e];
+            *(f32x4*)(smem + (lane & 31) * EP + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+        }
+        __syncthreads();
+        f32x4 xin[PER], sold[PER], val[PER];
+        bool ok[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * 256;
+            const int rl = idx / F4, c4 = idx % F4;
+            const int o = m * 32 + rl, t = t0 + o;
+            ok[u] = o < TTe && t < len;
+            val[u] = *(const f32x4*)(smem + rl * EP + c4 * 16);
+            xin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sold[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok[u]) xin[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+            if (ok[u] && p.mode >= 2) sold[u] = *(const f32x4*)(p.y + (brow + t) * C + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (!ok[u]) continue;
+            const int idx = tid + u * 256;
+            const int rl = idx / F4, c4 = idx % F4;
+            const long long off = (brow + t0 + m * 32 + rl) * C + c4 * 4;
+            f32x4 o = val[u] + xin[u];                 // x = xt + x
+            if (p.mode >= 2) o += sold[u];             // xs += x
+            if (p.mode == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
+            }
+            *(f32x4*)(p.y + off) = o;
+            if (p.mode == 3 && p.ya) {
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = rf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
+                *(uint2*)(p.ya + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+}
+
+bool vpair_supported(int C, int K, int dil) { return C == 128 && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5; }
+
+hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
+    if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
+    constexpr int CC = 128, PITCH = CC * 2 + 16;
+    const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
+    const int TTe = 128 - 2 * h2;
+    // staged rows + one spare tap for the activation prefetch; the xt phase needs 128 + (K-1) + 1 rows, the epilogue 32 fp32 rows
+    size_t rows = (size_t)128 + 2 * h1 + p.dil + 1;
+    if (rows < (size_t)128 + p.K + 1) rows = 128 + p.K + 1;
+    size_t lds = rows * PITCH;
+    const size_t ep = (size_t)32 * (CC * 4 + 16);
+    if (ep > lds) lds = ep;
+    auto kern = vpair_kernel<CC>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.T + TTe - 1) / TTe, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace dtts

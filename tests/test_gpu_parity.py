@@ -216,7 +216,8 @@ def test_missing_weight_fails_loudly(voc_sd):
 
 
 def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
-    """the fused ResBlock kernel (rblock.hip, stages with C <= 64) and the per-convolution path have the same bf16
+    """the fused kernels (rblock.hip: whole ResBlocks at C <= 64; vpair.hip: one ResBlock iteration at C = 128) and the
+    per-convolution path have the same bf16
     rounding POINTS (conv inputs), fp32 accumulation and fp32 residual; their fp32 summation order differs (the fused
     kernel starts the accumulator at the bias and accumulates conv2 into the residual registers), which flips an
     occasional bf16 rounding.  So: they agree to well below the bf16 noise floor, and both sit at the same distance
@@ -239,6 +240,7 @@ def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
         w = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), m).numpy()
         assert x.shape == y.shape == w.shape == (n * 256,)
         ex, ey = rms(x - w), rms(y - w)
-        assert rms(x - y) <= 0.5 * max(ex, ey), (rms(x - y), ex, ey)      # far below the bf16 noise of either path
+        # two independent bf16-noise realisations would sit sqrt(2) * e apart; the paths share every rounding point
+        assert rms(x - y) <= 0.75 * max(ex, ey), (rms(x - y), ex, ey)
         assert ex <= 1.15 * ey + 1e-5 and ey <= 1.15 * ex + 1e-5, (ex, ey)
         assert abs(rms(x) - rms(w)) <= 1e-4 and abs(rms(y) - rms(w)) <= 1e-4
