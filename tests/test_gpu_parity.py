@@ -244,3 +244,55 @@ def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
         assert rms(x - y) <= 0.75 * max(ex, ey), (rms(x - y), ex, ey)
         assert ex <= 1.15 * ey + 1e-5 and ey <= 1.15 * ex + 1e-5, (ex, ey)
         assert abs(rms(x) - rms(w)) <= 1e-4 and abs(rms(y) - rms(w)) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 4, 5
+def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc_bf16, oracle_voc_sd):
+    """BASELINE.json configs[3]: 1000-char input (T_w = 1002), teacher-forced 5 frames/char -> ~5k mel frames, B=1:
+    attention over 1002 words, every conv tiled over 5k..1.28M time steps, mel and waveform vs the oracle"""
+    from oracle import dict_tts_ref as ref
+    from oracle import hifigan_ref as href
+    st = synth.biaobei_struct()
+    ids = [w for s in st["sentences"] for w in s][:1000]
+    batch = synth.make_batch([ids], gc.SEED)
+    m2w = synth.teacher_mel2word(batch["word_tokens"], 5, 5)
+    assert batch["word_tokens"].shape[1] == 1002 and m2w.shape[1] == 5010
+    b = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], mel2word=T(m2w), z_p=lambda B, T4: T(synth.noise(21, B, T4)))
+    T_mel = want["mel_out"].shape[1]
+    assert T_mel == 5012
+    got = _run(acoustic, batch, z=T(synth.noise(21, 1, T_mel // 4)), mel2word=T(m2w))
+    assert (got["word_encoder_out"].cpu() - want["word_encoder_out"]).abs().max() <= 2e-4
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    mel = want["mel_out"][0].numpy()
+    wav = voc_bf16.spec2wav(mel)
+    wref = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel).numpy()
+    assert wav.shape == wref.shape == (5012 * 256,)
+    assert abs(rms(wav) - rms(wref)) <= 1e-4 and rms(wav - wref) <= 0.02 * rms(wref)
+
+
+def test_config5_dictionary_stress_mixed_lengths(acoustic, oracle_sd):
+    """BASELINE.json configs[4] (one GPU's share): B=32 mixed-length utterances (6..60 chars) drawn from the whole
+    dictionary structure with heteronyms over-sampled x5, word ids up to word_size=8000, every char forced to a sense"""
+    from oracle import dict_tts_ref as ref
+    st = synth.biaobei_struct()
+    rng = np.random.default_rng(5)
+    ids = np.array(sorted(st["entries"].keys()))
+    wts = np.array([5.0 if len(st["entries"][i]) > 1 else 1.0 for i in ids])
+    wts /= wts.sum()
+    sents = [rng.choice(ids, size=int(rng.integers(6, 61)), p=wts).tolist() for _ in range(32)]
+    batch = synth.make_batch(sents, gc.SEED, pron_every=3)
+    batch["word_tokens"][batch["word_tokens"] == synth.BOS_ID] = 7999          # highest row of the 8000-word table
+    b = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], z_p=lambda B, T4: T(synth.noise(31, B, T4)))
+    T_mel = want["mel_out"].shape[1]
+    got = _run(acoustic, batch, z=T(synth.noise(31, 32, T_mel // 4)))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"])
+    assert (got["pron_attn"].cpu() - want["pron_attn"]).abs().max() <= 1e-5
+    assert (got["dict_attn"].cpu() - want["dict_attn"]).abs().max() <= 1e-5
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    from dict_tts_amd.model import decode_pinyin_ids
+    for u in range(32):
+        assert decode_pinyin_ids(got["pron_attn"][u], batch["pinyin"][u]) == ref.decode_pinyin(want["pron_attn"][u], b["pinyin"][u])
