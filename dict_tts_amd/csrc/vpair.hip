@@ -12,6 +12,9 @@
 
 #include "rb_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace dtts {
 
 template <int C>
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
     {
-        constexpr int U = 4;
+        constexpr int U = 12;   // 2 batches for k=11: each batch exposes one HBM latency
         const int total = arows * F4;
         for (int base = tid; base < total; base += 256 * U) {
             f32x4 v[U];
@@ -113,8 +116,25 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
-    // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode
+    // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
+    // The global reads of slab m+1 are issued before slab m is processed (one exposed latency, not four).
     constexpr int PER = 32 * F4 / 256;
+    f32x4 xin[2][PER], sold[2][PER];
+    auto fetch = [&](int m, f32x4 (&xi)[PER], f32x4 (&so)[PER]) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * 256;
+            const int rl = idx / F4, c4 = idx % F4;
+            const int o = m * 32 + rl, t = t0 + o;
+            xi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            so[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < TTe && t < len) {
+                xi[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+                if (p.mode >= 2) so[u] = *(const f32x4*)(p.y + (brow + t) * C + c4 * 4);
+            }
+        }
+    };
+    fetch(0, xin[0], sold[0]);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (m) __syncthreads();
@@ -125,29 +145,17 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[m][0][4 * q + e];
             *(f32x4*)(smem + (lane & 31) * EP + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
         }
+        if (m + 1 < MT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
         __syncthreads();
-        f32x4 xin[PER], sold[PER], val[PER];
-        bool ok[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int idx = tid + u * 256;
             const int rl = idx / F4, c4 = idx % F4;
-            const int o = m * 32 + rl, t = t0 + o;
-            ok[u] = o < TTe && t < len;
-            val[u] = *(const f32x4*)(smem + rl * EP + c4 * 16);
-            xin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            sold[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok[u]) xin[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
-            if (ok[u] && p.mode >= 2) sold[u] = *(const f32x4*)(p.y + (brow + t) * C + c4 * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if (!ok[u]) continue;
-            const int idx = tid + u * 256;
-            const int rl = idx / F4, c4 = idx % F4;
-            const long long off = (brow + t0 + m * 32 + rl) * C + c4 * 4;
-            f32x4 o = val[u] + xin[u];                 // x = xt + x
-            if (p.mode >= 2) o += sold[u];             // xs += x
+            const int oo = m * 32 + rl, t = t0 + oo;
+            if (!(oo < TTe && t < len)) continue;
+            const long long off = (brow + t) * C + c4 * 4;
+            f32x4 o = *(const f32x4*)(smem + rl * EP + c4 * 16) + xin[m & 1][u];   // x = xt + x
+            if (p.mode >= 2) o += sold[m & 1][u];                                   // xs += x
             if (p.mode == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
@@ -176,10 +184,11 @@ hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
+    if (const char* e = getenv("DTTS_VPAIR_LDS")) lds = std::max<size_t>(lds, (size_t)atoi(e) * 1024);  // occupancy experiment
     auto kern = vpair_kernel<CC>;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured = true;
     }
