@@ -674,7 +674,7 @@ VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* len
     p.pad = L.pad;
     p.slope = 1.f;
     p.div = 1.f;
-    static const int dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
+    static const int dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) & 15 : 0;
     p.dbg = dbg;
     return p;
 }
@@ -773,7 +773,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 rp.div = (float)nk;
                 rp.slope = last_stage ? 0.01f : 0.1f;
                 rp.Sa = Sa;
-                rp.dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) >> 4 : 0;
+                rp.dbg = getenv("DTTS_VCONV_DBG") ? (atoi(getenv("DTTS_VCONV_DBG")) >> 4) & 15 : 0;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
                 LAUNCH(rblock_launch(rp, ch, s));
@@ -797,6 +797,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                     vp.dil = c1[mth].dil;
                     vp.div = (float)nk;
                     vp.slope = last_stage ? 0.01f : 0.1f;
+                    vp.dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) >> 8 : 0;
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;

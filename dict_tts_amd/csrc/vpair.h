@@ -17,6 +17,7 @@ struct VPairParams {
     int B, T, K, dil;
     int mode;
     float div, slope;
+    int dbg;              // tuning ablations (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
 };
 
 bool vpair_supported(int C, int K, int dil);

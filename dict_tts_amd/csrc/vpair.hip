@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     const int len = p.lens ? p.lens[b] : p.T;
     if (t0 >= len) return;
     const long long brow = (long long)b * p.T;
-    const int S = p.K * NKG;
+    const int S = (p.dbg & 1) ? 0 : p.K * NKG;
 
     uint4 ring[4][NT];
     const size_t wlane = (size_t)wc * 64 + lane;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     // ---- stage bf16(leaky_relu(x)) for rows [t0 - h2 - h1, t0 - h2 + TT + h1) ; zero outside the utterance
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
-    {
+    if (!(p.dbg & 4)) {
         constexpr int U = 12;   // 2 batches for k=11: each batch exposes one HBM latency
         const int total = arows * F4;
         for (int base = tid; base < total; base += 256 * U) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     __syncthreads();   // every wave is done reading the x tile
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < ((p.dbg & 8) ? 0 : MT); ++m) {
         const int r = m * 32 + (lane & 31);
         const int t = t0 - h2 + r;
         const bool inb = t >= 0 && t < len;
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
+        return;
+    }
     // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
     // The global reads of slab m+1 are issued before slab m is processed (one exposed latency, not four).
     constexpr int PER = 32 * F4 / 256;
