@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of mels when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dict-table", action="store_true",
+                    help="resident dictionary table: batches carry entry ids instead of keys/values tensors (SURVEY 8f-1)")
     ap.add_argument("--phases", action="store_true", help="debug: per-phase device/host times on stderr")
     args = ap.parse_args()
 
@@ -108,9 +110,17 @@ def main():
     # ---- this rank's batch, resident in HBM
     st = synth.biaobei_struct()
     sent = [st["sentences"][(rank * args.batch + i) % len(st["sentences"])] for i in range(args.batch)]
-    batch = {k: T(v).to(dev) for k, v in synth.make_batch(sent, 1234).items()}
-    B, T_w = batch["word_tokens"].shape
-    L_k = batch["keys"].shape[2]
+    if args.dict_table:
+        table = synth.dict_table(1234)
+        m.upload_dict_table(table)
+        ib = synth.make_id_batch(sent, table)
+        batch = {k: T(v).to(dev) for k, v in ib.items() if k not in ("L_k", "P")}
+        B, T_w = batch["word_tokens"].shape
+        L_k, P_ = ib["L_k"], ib["P"]
+    else:
+        batch = {k: T(v).to(dev) for k, v in synth.make_batch(sent, 1234).items()}
+        B, T_w = batch["word_tokens"].shape
+        L_k, P_ = batch["keys"].shape[2], batch["pinyin"].shape[2]
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     z_all = torch.randn(B, 16, 4096, generator=gen).to(dev)  # prior noise, sliced to T_mel/4 each step
     CAP = 1548                                                # max_frames (egs/egs_bases/tts/base.yaml:45)
@@ -130,9 +140,13 @@ def main():
             h0 = time.perf_counter()
             ev[0].record()
         ptr = lambda t: t.data_ptr()
-        T_mel = m.ctx.text2mel_encode(ptr(batch["word_tokens"]), ptr(batch["keys"]), ptr(batch["values"]),
-                                      ptr(batch["key_map"]), ptr(batch["pinyin"]), ptr(batch["pinyin_map"]),
-                                      ptr(batch["pron_modified"]), None, B, T_w, L_k, batch["pinyin"].shape[2], stream)
+        if args.dict_table:
+            T_mel = m.ctx.text2mel_encode_ids(ptr(batch["word_tokens"]), ptr(batch["entry_ids"]), ptr(batch["pron_modified"]),
+                                              None, B, T_w, L_k, P_, stream)
+        else:
+            T_mel = m.ctx.text2mel_encode(ptr(batch["word_tokens"]), ptr(batch["keys"]), ptr(batch["values"]),
+                                          ptr(batch["key_map"]), ptr(batch["pinyin"]), ptr(batch["pinyin_map"]),
+                                          ptr(batch["pron_modified"]), None, B, T_w, L_k, P_, stream)
         if args.phases:
             h1 = time.perf_counter()
             ev[1].record()
@@ -225,7 +239,8 @@ def main():
                                    "predicted durations (~22 frames/char)", "utterances_per_gpu": B, "T_w": T_w, "L_k": L_k,
                        "T_mel_padded": T_mel, "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
                        "parallelism": f"dp{world}" + ("+allgather(mel)" if gather_on else ""),
-                       "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision},
+                       "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision,
+                       "dictionary_input": "resident table + ids" if args.dict_table else "keys/values tensors [B,T_w,L_k,768] (reference API)"},
             "audio_samples_per_sec": samples, "rtf": 22050.0 / samples,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -18,7 +18,7 @@ OUT_PRON_ATTN, OUT_DUR, OUT_MEL2WORD, OUT_DICT_ATTN, OUT_WORD_ENCODER_OUT, OUT_X
 TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
 EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
-           "dtts_finalize_weights", "dtts_text2mel_encode", "dtts_text2mel_decode", "dtts_text2mel_fetch",
+           "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
 
 
@@ -64,6 +64,8 @@ def load_library(path=None):
     lib.dtts_finalize_weights.argtypes = [vp, i32]
     lib.dtts_text2mel_encode.argtypes = [vp] + [vp] * 8 + [i32] * 5 + [C.POINTER(C.c_int32), vp]
     lib.dtts_text2mel_decode.argtypes = [vp, vp, vp, vp]
+    lib.dtts_text2mel_encode_ids.argtypes = [vp, vp, vp, vp, vp] + [i32] * 5 + [C.POINTER(C.c_int32), vp]
+    lib.dtts_dict_table_upload.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.dtts_text2mel_fetch.argtypes = [vp, i32, vp, vp]
     lib.dtts_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.dtts_length_regulate.argtypes = [vp, vp, vp, i32, i32, vp, i32, C.POINTER(C.c_int32), vp]
@@ -134,6 +136,25 @@ class Context:
         self._chk(self.lib.dtts_text2mel_encode(self.h, word_tokens, keys, values, key_map, pinyin, pinyin_map,
                                                 pron_modified or None, m2w_ptr, T_m2w, B, T_w, L_k, P, C.byref(t_mel),
                                                 stream), "dtts_text2mel_encode")
+        return t_mel.value
+
+    def dict_table_upload(self, tok_off, keys, values, key_map, pin_off, pinyin, pinyin_map):
+        """numpy arrays (host): tok_off/pin_off int32 [n+1], keys/values f32 [sum_L,768] (values may be None = keys),
+        key_map f32 [sum_L], pinyin / pinyin_map int64 [sum_P]"""
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        tok_off, pin_off = c(tok_off, np.int32), c(pin_off, np.int32)
+        keys, key_map = c(keys, np.float32), c(key_map, np.float32)
+        values = None if values is None else c(values, np.float32)
+        pinyin, pinyin_map = c(pinyin, np.int64), c(pinyin_map, np.int64)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._chk(self.lib.dtts_dict_table_upload(self.h, len(tok_off) - 1, p(tok_off), p(keys), p(values), p(key_map),
+                                                  p(pin_off), p(pinyin), p(pinyin_map)), "dtts_dict_table_upload")
+
+    def text2mel_encode_ids(self, word_tokens, entry_ids, pron_modified, mel2word, B, T_w, L_k, P, stream):
+        t_mel = C.c_int32(0)
+        m2w_ptr, T_m2w = (mel2word if mel2word else (None, 0))
+        self._chk(self.lib.dtts_text2mel_encode_ids(self.h, word_tokens, entry_ids, pron_modified or None, m2w_ptr, T_m2w, B,
+                                                    T_w, L_k, P, C.byref(t_mel), stream), "dtts_text2mel_encode_ids")
         return t_mel.value
 
     def text2mel_decode(self, z_p, mel_out, stream):

@@ -128,6 +128,11 @@ struct dtts_ctx {
     int64_t* m2w = nullptr;
     int *mel_lens = nullptr, *lens = nullptr;
     TimerSlot timers[3];
+    // ---- resident dictionary table (dtts_dict_table_upload)
+    int t_entries = 0;
+    int *t_off = nullptr, *t_poff = nullptr, *t_pmmax = nullptr;
+    float *t_keys = nullptr, *t_values = nullptr, *t_key_map = nullptr;
+    int64_t *t_pinyin = nullptr, *t_pinyin_map = nullptr;
 };
 
 static std::string g_create_err;
@@ -1086,15 +1091,17 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     return DTTS_OK;
 }
 
-int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values,
-                         const float* key_map, const int64_t* pinyin, const int64_t* pinyin_map,
-                         const int64_t* pron_modified, const int64_t* mel2word, int T_m2w, int B, int T_w, int L_k, int P,
-                         int32_t* T_mel_host, dtts_stream stream) {
+static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values,
+                       const float* key_map, const int64_t* pinyin, const int64_t* pinyin_map, const int32_t* entry_ids,
+                       const int64_t* pron_modified, const int64_t* mel2word, int T_m2w, int B, int T_w, int L_k, int P,
+                       int32_t* T_mel_host, dtts_stream stream) {
     if (!h) return DTTS_E_INVAL;
     if (!h->acoustic_ready) return fail(h, DTTS_E_STATE, "acoustic weights not finalized");
-    if (!word_tokens || !keys || !values || !key_map || !pinyin || !pinyin_map || !T_mel_host || B <= 0 || T_w <= 0 ||
-        L_k <= 0 || P <= 0 || L_k > 1024 || P > 64)
+    const bool tensors_ok = keys && values && key_map && pinyin && pinyin_map;
+    if (!word_tokens || (!entry_ids && !tensors_ok) || !T_mel_host || B <= 0 || T_w <= 0 || L_k <= 0 || P <= 0 || L_k > 1024 ||
+        P > 64)
         return fail(h, DTTS_E_INVAL, "dtts_text2mel_encode: bad argument (B=%d T_w=%d L_k=%d P=%d)", B, T_w, L_k, P);
+    if (entry_ids && !h->t_entries) return fail(h, DTTS_E_STATE, "dtts_text2mel_encode_ids before dtts_dict_table_upload");
     hipStream_t s = (hipStream_t)stream;
     const dtts_config& c = h->cfg;
     const int C = c.hidden_size, D = c.gloss_dim, F = 4 * C;
@@ -1145,8 +1152,18 @@ int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens, const float*
         LAUNCH(conv1d_launch(h->s2_q, p, s));
         p = base_params(q, C, B, T_w, T_w, qk, D);
         LAUNCH(conv1d_launch(h->s2_kT, p, s));
-        LAUNCH(max_i64_launch(pinyin_map, (long long)rows * P, pm_max, s));
+        if (entry_ids) LAUNCH(max_entry_pm_launch(entry_ids, h->t_pmmax, (long long)rows, pm_max, s));
+        else LAUNCH(max_i64_launch(pinyin_map, (long long)rows * P, pm_max, s));
         S2paArgs a;
+        memset(&a, 0, sizeof a);
+        a.entry = entry_ids;
+        a.t_off = h->t_off;
+        a.t_keys = h->t_keys;
+        a.t_values = h->t_values;
+        a.t_key_map = h->t_key_map;
+        a.t_poff = h->t_poff;
+        a.t_pinyin = h->t_pinyin;
+        a.t_pinyin_map = h->t_pinyin_map;
         a.qk = qk;
         a.keys = keys;
         a.values = values;
@@ -1226,6 +1243,57 @@ int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens, const float*
     h->T_mel = T_mel;
     *T_mel_host = T_mel;
     h->encoded = true;
+    return DTTS_OK;
+}
+
+int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values,
+                         const float* key_map, const int64_t* pinyin, const int64_t* pinyin_map,
+                         const int64_t* pron_modified, const int64_t* mel2word, int T_m2w, int B, int T_w, int L_k, int P,
+                         int32_t* T_mel_host, dtts_stream stream) {
+    if (h && !(keys && values && key_map && pinyin && pinyin_map))
+        return fail(h, DTTS_E_INVAL, "dtts_text2mel_encode: null dictionary tensor");
+    return encode_impl(h, word_tokens, keys, values, key_map, pinyin, pinyin_map, nullptr, pron_modified, mel2word, T_m2w, B, T_w,
+                       L_k, P, T_mel_host, stream);
+}
+
+int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens, const int32_t* entry_ids, const int64_t* pron_modified,
+                             const int64_t* mel2word, int T_m2w, int B, int T_w, int L_k, int P, int32_t* T_mel_host,
+                             dtts_stream stream) {
+    if (h && !entry_ids) return fail(h, DTTS_E_INVAL, "dtts_text2mel_encode_ids: null entry ids");
+    return encode_impl(h, word_tokens, nullptr, nullptr, nullptr, nullptr, nullptr, entry_ids, pron_modified, mel2word, T_m2w, B,
+                       T_w, L_k, P, T_mel_host, stream);
+}
+
+int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off, const float* keys, const float* values,
+                           const float* key_map, const int32_t* pin_off, const int64_t* pinyin, const int64_t* pinyin_map) {
+    if (!h || n_entries <= 0 || !tok_off || !keys || !key_map || !pin_off || !pinyin || !pinyin_map)
+        return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: bad argument");
+    const int D = h->cfg.gloss_dim;
+    const size_t nL = (size_t)tok_off[n_entries], nP = (size_t)pin_off[n_entries];
+    for (int e = 0; e < n_entries; ++e)
+        if (tok_off[e + 1] < tok_off[e] || pin_off[e + 1] < pin_off[e])
+            return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: offsets must be non-decreasing (entry %d)", e);
+    std::vector<int> pmmax(n_entries, 0);
+    for (int e = 0; e < n_entries; ++e)
+        for (int p = pin_off[e]; p < pin_off[e + 1]; ++p) pmmax[e] = std::max(pmmax[e], (int)pinyin_map[p]);
+    auto up = [&](const void* src, size_t bytes) -> void* {
+        void* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        h->allocs.push_back(d);
+        return d;
+    };
+    h->t_off = (int*)up(tok_off, sizeof(int) * (n_entries + 1));
+    h->t_poff = (int*)up(pin_off, sizeof(int) * (n_entries + 1));
+    h->t_pmmax = (int*)up(pmmax.data(), sizeof(int) * n_entries);
+    h->t_keys = (float*)up(keys, nL * D * sizeof(float));
+    h->t_values = values ? (float*)up(values, nL * D * sizeof(float)) : h->t_keys;  // the reference stores key == value
+    h->t_key_map = (float*)up(key_map, nL * sizeof(float));
+    h->t_pinyin = (int64_t*)up(pinyin, nP * sizeof(int64_t));
+    h->t_pinyin_map = (int64_t*)up(pinyin_map, nP * sizeof(int64_t));
+    if (!h->t_off || !h->t_poff || !h->t_pmmax || !h->t_keys || !h->t_values || !h->t_key_map || !h->t_pinyin || !h->t_pinyin_map)
+        return fail(h, DTTS_E_NOMEM, "dtts_dict_table_upload: device allocation / copy failed");
+    h->t_entries = n_entries;
     return DTTS_OK;
 }
 

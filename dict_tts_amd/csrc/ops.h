@@ -43,9 +43,23 @@ struct S2paArgs {
     float* pron_attn;             // [B*T_w][P]
     float* pron;                  // [B*T_w][H]
     int B, T_w, L_k, P, D, H, n_pinyin, language_zh;
+    // resident-dictionary mode (entry != null): keys/values/key_map/pinyin/pinyin_map above are ignored and every word
+    // row is gathered from the device-resident ragged table by its entry id.  entry[row] >= 0: dictionary entry;
+    // -1: the BOS / last row the collater pads onto every sentence (zero vectors, key_map and pinyin_map all 1,
+    // tasks/tts/dataset_utils.py:287-300); -2: batch padding (everything zero / masked).
+    const int* entry;          // [B*T_w]
+    const int* t_off;          // [n_entries + 1] gloss-token offsets
+    const float* t_keys;       // [sum_L][D]
+    const float* t_values;     // [sum_L][D]
+    const float* t_key_map;    // [sum_L]
+    const int* t_poff;         // [n_entries + 1] pinyin-token offsets
+    const int64_t* t_pinyin;   // [sum_P]
+    const int64_t* t_pinyin_map;
 };
 hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s);
 hipError_t max_i64_launch(const int64_t* x, long long n, int* out, hipStream_t s);
+// table mode: out = max over rows of the entry's max pinyin_map (t_pmmax[e]; 1 for entry -1, 0 for -2)
+hipError_t max_entry_pm_launch(const int* entry, const int* t_pmmax, long long n, int* out, hipStream_t s);
 
 // y = a + b (elementwise, n floats, n % 4 == 0)
 hipError_t add_launch(const float* a, const float* b, float* y, long long n, hipStream_t s);

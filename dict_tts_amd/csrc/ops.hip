@@ -183,8 +183,39 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     const int row = blockIdx.x;  // b * T_w + t
     const int b = row / a.T_w, t = row % a.T_w;
     const int L = a.L_k, D4 = a.D / 4;
-    const float* kmr = a.key_map + (long long)row * L;
-    for (int l = tid; l < L; l += 256) km[l] = kmr[l];
+    // row sources: the collated tensors, or the resident table
+    const float* kmr = nullptr;
+    const f32x4* kb = nullptr;
+    const f32x4* vb = nullptr;
+    const int64_t* pin = nullptr;
+    const int64_t* pmr = nullptr;
+    int Lrow = L, Prow = a.P;
+    int special = 0;  // -1 / -2 in table mode
+    if (a.entry) {
+        const int e = a.entry[row];
+        if (e >= 0) {
+            const int o = a.t_off[e];
+            Lrow = min(a.t_off[e + 1] - o, L);
+            kmr = a.t_key_map + o;
+            kb = (const f32x4*)(a.t_keys + (long long)o * a.D);
+            vb = (const f32x4*)(a.t_values + (long long)o * a.D);
+            const int po = a.t_poff[e];
+            Prow = min(a.t_poff[e + 1] - po, a.P);
+            pin = a.t_pinyin + po;
+            pmr = a.t_pinyin_map + po;
+        } else {
+            special = e;
+            Lrow = 0;
+            Prow = 0;
+        }
+    } else {
+        kmr = a.key_map + (long long)row * L;
+        kb = (const f32x4*)(a.keys + (long long)row * L * a.D);
+        vb = (const f32x4*)(a.values + (long long)row * L * a.D);
+        pin = a.pinyin + (long long)row * a.P;
+        pmr = a.pinyin_map + (long long)row * a.P;
+    }
+    for (int l = tid; l < L; l += 256) km[l] = l < Lrow ? kmr[l] : (special == -1 ? 1.f : 0.f);
     // the query, 12 floats per lane
     f32x4 q[S2PA_DMAX4];
     const f32x4* qp = (const f32x4*)(a.qk + (long long)row * a.D);
@@ -192,10 +223,13 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     for (int c = 0; c < S2PA_DMAX4; ++c) q[c] = (lane + 64 * c < D4) ? qp[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     // logits (rows with key_map == 0 are masked regardless of their content: not read at all)
-    const f32x4* kb = (const f32x4*)(a.keys + (long long)row * L * a.D);
     for (int l = wave; l < L; l += 4) {
         if (km[l] == 0.f) {
             if (lane == 0) lg[l] = -1e9f;
+            continue;
+        }
+        if (l >= Lrow) {   // table mode, BOS / last row: zero gloss vector
+            if (lane == 0) lg[l] = 0.f;
             continue;
         }
         const f32x4* kr = kb + (long long)l * D4;
@@ -238,8 +272,7 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     f32x4 acc[S2PA_DMAX4];
 #pragma unroll
     for (int c = 0; c < S2PA_DMAX4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* vb = (const f32x4*)(a.values + (long long)row * L * a.D);
-    for (int l = wave; l < L; l += 4) {
+    for (int l = wave; l < Lrow; l += 4) {   // rows >= Lrow are zero vectors (table mode) or do not exist
         const float w = lg[l];
         if (w == 0.f) continue;
         const f32x4* vr = vb + (long long)l * D4;
@@ -260,10 +293,8 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     __syncthreads();
     for (int c = tid; c < a.D; c += 256) a.wv[(long long)row * a.D + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
     // pronunciation weights
-    const int64_t* pin = a.pinyin + (long long)row * a.P;
-    const int64_t* pmr = a.pinyin_map + (long long)row * a.P;
     if (tid < a.P && tid < 64) {
-        const long long pm = pmr[tid];
+        const long long pm = tid < Prow ? pmr[tid] : (special == -1 ? 1 : 0);
         float w = (pm >= 1 && pm < 16) ? sense[pm] : 0.f;
         if (a.language_zh && a.pron_modified) {
             const long long mod = a.pron_modified[row];
@@ -281,7 +312,7 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     for (int c = tid; c < a.H; c += 256) {
         float s = 0.f;
         for (int p = 0; p < a.P; ++p) {
-            long long id = pin[p];
+            long long id = p < Prow ? pin[p] : 0;
             if (id < 0 || id >= a.n_pinyin) id = 0;
             s += pw[p] * a.pinyin_emb[id * a.H + c];
         }
@@ -301,6 +332,23 @@ __global__ void max_i64_kernel(const int64_t* x, long long n, int* out) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+__global__ void max_entry_pm_kernel(const int* entry, const int* t_pmmax, long long n, int* out) {
+    int m = 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int e = entry[i];
+        m = max(m, e >= 0 ? t_pmmax[e] : (e == -1 ? 1 : 0));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+hipError_t max_entry_pm_launch(const int* entry, const int* t_pmmax, long long n, int* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+    hipLaunchKernelGGL(max_entry_pm_kernel, dim3(blocks), dim3(256), 0, s, entry, t_pmmax, n, out);
+    return hipGetLastError();
 }
 hipError_t max_i64_launch(const int64_t* x, long long n, int* out, hipStream_t s) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);

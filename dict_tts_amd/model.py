@@ -94,10 +94,35 @@ class PortaSpeech_dict(torch.nn.Module):
         assert key_map.shape == (B, T_w, L_k) and pinyin.shape == pinyin_map.shape == (B, T_w, P)
         stream = torch.cuda.current_stream().cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
-        T_mel = self.ctx.text2mel_encode(ptr(word_tokens), ptr(keys), ptr(values), ptr(key_map), ptr(pinyin),
+        return self._finish(self.ctx.text2mel_encode(ptr(word_tokens), ptr(keys), ptr(values), ptr(key_map), ptr(pinyin),
                                          ptr(pinyin_map), ptr(pron_modified),
                                          (ptr(mel2word), mel2word.shape[1]) if mel2word is not None else None, B, T_w,
-                                         L_k, P, stream)
+                                         L_k, P, stream), z_p, B, T_w, L_k, P)
+
+    def upload_dict_table(self, table):
+        """make the dictionary resident in HBM (dict_tts_amd/synth.py:dict_table layout = the reference's dict_embed items)"""
+        self.ctx.dict_table_upload(table["tok_off"], table["keys"], table.get("values"), table["key_map"], table["pin_off"],
+                                   table["pinyin"], table["pinyin_map"])
+
+    def forward_ids(self, word_tokens, entry_ids, pron_modified, L_k, P, mel2word=None, z_p=None):
+        """forward(infer=True) with the dictionary tensors replaced by ids into the resident table"""
+        dev = self.device
+        word_tokens = word_tokens.to(device=dev, dtype=torch.int64).contiguous()
+        entry_ids = entry_ids.to(device=dev, dtype=torch.int32).contiguous()
+        pron_modified = None if pron_modified is None else pron_modified.to(device=dev, dtype=torch.int64).contiguous()
+        mel2word = None if mel2word is None else mel2word.to(device=dev, dtype=torch.int64).contiguous()
+        B, T_w = word_tokens.shape
+        stream = torch.cuda.current_stream().cuda_stream
+        ptr = lambda t: None if t is None else t.data_ptr()
+        T_mel = self.ctx.text2mel_encode_ids(ptr(word_tokens), ptr(entry_ids), ptr(pron_modified),
+                                             (ptr(mel2word), mel2word.shape[1]) if mel2word is not None else None, B, T_w,
+                                             int(L_k), int(P), stream)
+        return self._finish(T_mel, z_p, B, T_w, int(L_k), int(P))
+
+    def _finish(self, T_mel, z_p, B, T_w, L_k, P):
+        dev = self.device
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        stream = torch.cuda.current_stream().cuda_stream
         Z = self.cfg.latent_size
         if z_p is None:
             z_p = torch.distributions.Normal(0, 1).sample([B, Z, T_mel // 4])  # fvae_semantics.py:110

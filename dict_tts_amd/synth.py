@@ -269,3 +269,48 @@ def random_mel(seed, T, name="mel"):
     # smooth along time so that it resembles a spectrogram rather than white noise
     m[1:] = 0.6 * m[1:] + 0.4 * m[:-1]
     return np.clip(m, -6.0, 1.5).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# resident dictionary table: the ragged form of the reference's ``dict_embed`` indexed dataset
+# ----------------------------------------------------------------------------------------------------------
+def dict_table(seed=1234, entries=None):
+    """-> dict(ids, tok_off, keys, key_map, pin_off, pinyin, pinyin_map, L, P): every entry of the structure file, in
+    ascending word-id order; ``ids[word_id]`` is the table row of a word."""
+    entries = biaobei_struct()["entries"] if entries is None else entries
+    order = sorted(entries)
+    ids = {w: i for i, w in enumerate(order)}
+    items = [dict_entry(w, seed, entries) for w in order]
+    tok_off = np.zeros(len(order) + 1, np.int32)
+    pin_off = np.zeros(len(order) + 1, np.int32)
+    for i, (emb, km, py, pm) in enumerate(items):
+        tok_off[i + 1] = tok_off[i] + emb.shape[0]
+        pin_off[i + 1] = pin_off[i] + py.shape[0]
+    return {"ids": ids, "tok_off": tok_off, "pin_off": pin_off,
+            "keys": np.concatenate([it[0] for it in items]), "key_map": np.concatenate([it[1] for it in items]),
+            "pinyin": np.concatenate([it[2] for it in items]), "pinyin_map": np.concatenate([it[3] for it in items]),
+            "L": np.diff(tok_off), "P": np.diff(pin_off)}
+
+
+def make_id_batch(sentences, table, pron_every=7):
+    """the id-only form of make_batch(): word_tokens [B,T_w] i64, entry_ids [B,T_w] i32 (-1 BOS / last row, -2 batch
+    padding), pron_modified [B,T_w] i64 and the batch maxima L_k, P the collated tensors would have"""
+    B = len(sentences)
+    Tw = max(len(s) for s in sentences) + 2
+    word_tokens = np.zeros((B, Tw), np.int64)
+    entry = np.full((B, Tw), -2, np.int32)
+    pron_modified = np.zeros((B, Tw), np.int64)
+    L_k, P, n_multi = 1, 1, 0
+    for b, s in enumerate(sentences):
+        word_tokens[b, :len(s) + 2] = [BOS_ID] + list(s) + [EOS_ID]
+        for t, w in enumerate(s):
+            e = table["ids"][w]
+            entry[b, t + 1] = e
+            L_k, P = max(L_k, int(table["L"][e])), max(P, int(table["P"][e]))
+            if table["pinyin_map"][table["pin_off"][e]:table["pin_off"][e + 1]].max() >= 2:
+                n_multi += 1
+                if pron_every and n_multi % pron_every == 0:
+                    pron_modified[b, t + 1] = 2
+    entry[:, 0] = -1
+    entry[:, -1] = -1
+    return {"word_tokens": word_tokens, "entry_ids": entry, "pron_modified": pron_modified, "L_k": L_k, "P": P}

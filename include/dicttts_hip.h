@@ -117,6 +117,26 @@ int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const fl
                          int P, int32_t* T_mel_host, dtts_stream stream);
 
 /*
+ * Resident dictionary: the reference ships keys + values [B,T_w,L_k,768] f32 host->device for every
+ * batch (tasks/tts/dataset_utils.py:305-330 looks every character up in the ``dict_embed`` indexed dataset and pads) —
+ * ~1.5 GB at B=60.  Uploaded once, the ragged table (one entry per dictionary word: gloss embeddings [L_e,768],
+ * key_map [L_e], pinyin / pinyin_map [P_e]; items of data_gen/tts/binarizer_zh.py:301-309) stays in HBM and a batch
+ * carries only ids.  All pointers are HOST pointers; values may be NULL (the reference stores value == key).
+ */
+int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off_host, const float* keys_host,
+                           const float* values_host, const float* key_map_host, const int32_t* pin_off_host,
+                           const int64_t* pinyin_host, const int64_t* pinyin_map_host);
+/*
+ * dtts_text2mel_encode with the dictionary tensors replaced by entry ids [B,T_w] i32 (device): >= 0 a table entry,
+ * -1 the BOS / last row the collater pads onto every sentence (zero vectors, key_map = pinyin_map = 1), -2 batch
+ * padding.  L_k / P are the batch maxima the collated tensors would have had (they size dict_attn / pron_attn).
+ * Results are identical to dtts_text2mel_encode on the tensors collated from the same table.
+ */
+int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
+                             const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k,
+                             int P, int32_t* T_mel_host, dtts_stream stream);
+
+/*
  * Acoustic model, phase 2 — replaces the gather-expand and run_decoder (model.py:105-121,
  * fvae_semantics.py:109-115): z_p [B,latent,T_mel/4] f32 is the prior sample (the reference draws it from the
  * CPU RNG; here it is an explicit input).  mel_out [B,T_mel,80] f32.

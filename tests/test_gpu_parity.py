@@ -296,3 +296,30 @@ def test_config5_dictionary_stress_mixed_lengths(acoustic, oracle_sd):
     from dict_tts_amd.model import decode_pinyin_ids
     for u in range(32):
         assert decode_pinyin_ids(got["pron_attn"][u], batch["pinyin"][u]) == ref.decode_pinyin(want["pron_attn"][u], b["pinyin"][u])
+
+
+# ------------------------------------------------------------------------------------------------ resident dictionary
+def test_resident_dictionary_ids_equal_collated_tensors(acoustic):
+    """dtts_dict_table_upload + dtts_text2mel_encode_ids (batches carry only ids) must reproduce
+    dtts_text2mel_encode on the tensors DictTTSDataset.collater would build from the same table — bit for bit, since
+    the same kernels read the same numbers: ragged lengths, heteronyms, forced senses, an UNK (zero) entry."""
+    st = synth.biaobei_struct()
+    entries = dict(st["entries"])
+    unk = 7000
+    entries[unk] = [[3, 0, -1]]                       # a char absent from zh-dict.json: the 3-token zero entry
+    table = synth.dict_table(gc.SEED, entries)
+    acoustic.upload_dict_table(table)
+    sents = [st["sentences"][5], st["sentences"][9][:5] + [unk], st["sentences"][40], st["sentences"][41][:3]]
+    tb = synth.make_batch(sents, gc.SEED, entries, pron_every=2)
+    ib = synth.make_id_batch(sents, table, pron_every=2)
+    assert np.array_equal(tb["word_tokens"], ib["word_tokens"]) and np.array_equal(tb["pron_modified"], ib["pron_modified"])
+    assert tb["keys"].shape[2] == ib["L_k"] and tb["pinyin"].shape[2] == ib["P"]
+    ra = acoustic((T(tb["word_tokens"]), None), T(tb["pron_modified"]), (None,) * 3, None, None,
+                  (T(tb["keys"]), T(tb["values"]), T(tb["key_map"]), T(tb["pinyin"]), T(tb["pinyin_map"])), infer=True)
+    zp = ra["z_p_in"]
+    rb = acoustic.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"], z_p=zp)
+    for k in ("mel2word", "dur", "pron_attn", "dict_attn", "word_encoder_out", "mel_out"):
+        assert torch.equal(ra[k], rb[k]), k
+    ctx = abi.Context()
+    with pytest.raises(abi.DttsError, match="not finalized|before dtts_dict_table_upload"):
+        ctx.text2mel_encode_ids(1, 1, None, None, 1, 4, 8, 2, None)
