@@ -160,7 +160,9 @@ def main():
         m.ctx.fetch(abi.OUT_MEL_LENS, lens.data_ptr(), stream)
         work = None
         if gather_on:
-            mel_pad[:, :T_mel] = mel[:, :CAP]
+            n_cp = min(T_mel, CAP)
+            mel_pad[:, :n_cp] = mel[:, :n_cp]
+            mel_pad[:, n_cp:].zero_()
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 work = dist.all_gather_into_tensor(mel_all, mel_pad, async_op=True)
