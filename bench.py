@@ -89,13 +89,21 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # test hook (1-GPU box): DTTS_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and uses gloo, so that the N>1 control
+    # flow (rendezvous, barriers, max-over-ranks timing, frame all-reduce) can be exercised without N GPUs
+    one_dev = os.environ.get("DTTS_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     # ---- weights (random-init of the real architecture) and the acoustic model / vocoder behind the reference APIs
@@ -124,7 +132,7 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     z_all = torch.randn(B, 16, 4096, generator=gen).to(dev)  # prior noise, sliced to T_mel/4 each step
     CAP = 1548                                                # max_frames (egs/egs_bases/tts/base.yaml:45)
-    gather_on = world > 1 and not args.no_gather
+    gather_on = world > 1 and not args.no_gather and not one_dev
     if gather_on:
         mel_pad = torch.zeros(B, CAP, 80, device=dev)
         mel_all = torch.empty(world * B, CAP, 80, device=dev)
