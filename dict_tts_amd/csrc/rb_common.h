@@ -15,6 +15,22 @@ __device__ __forceinline__ unsigned rf2bf(float f) {  // round-to-nearest-even f
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> one dword of two bf16 (round-to-nearest-even), a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, v);
+}
+// leaky_relu for 0 <= slope <= 1 as max(a, a * slope): v_mul + v_max (the asm keeps hipcc from adding the
+// canonicalising v_max a,a in front of fmaxf; NaNs do not occur on this path)
+__device__ __forceinline__ float lrelu(float a, float slope) {
+    float r;
+    const float b = a * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 constexpr int RB_GUARD = 40;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap + one prefetched tap, dilation 5)
 
 // acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]

@@ -104,13 +104,8 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    unsigned h[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = v[m][n][4 * q + e];
-                        h[e] = rf2bf(fmaxf(a, a * 0.1f));  // leaky_relu, slope 0.1 < 1
-                    }
-                    uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    uint2 pk = make_uint2(pack2bf(lrelu(v[m][n][4 * q], 0.1f), lrelu(v[m][n][4 * q + 1], 0.1f)),
+                                          pack2bf(lrelu(v[m][n][4 * q + 2], 0.1f), lrelu(v[m][n][4 * q + 3], 0.1f)));
                     if (!inb) pk = make_uint2(0, 0);
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
@@ -213,10 +208,8 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
             }
             *(f32x4*)dst = o;
             if (p.mode == 2 && p.Sa) {
-                unsigned h[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = rf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
-                *(uint2*)(p.Sa + (brow + t) * C + c4 * 4) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *(uint2*)(p.Sa + (brow + t) * C + c4 * 4) =
+                    make_uint2(pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope)));
             }
         }
     }

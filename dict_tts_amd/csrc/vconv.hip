@@ -12,12 +12,10 @@
 //   * dual-output epilogue: fp32 residual stream + bf16 leaky_relu copy for the next convolution.
 // Same packed-weight format as conv1d.hip (context.hip:pack_conv), same contraction, same rounding points.
 #include "vconv.h"
+#include "rb_common.h"
 
 namespace dtts {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even fp32 -> bf16 bits (hardware convert)
     const __bf16 h = (__bf16)f;
@@ -194,12 +192,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
                         for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]);
                     }
                     if (p.yf) *(f32x4*)(p.yf + off[u] * p.ldyf + co) = o;
-                    if (p.ya) {
-                        unsigned h[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = vf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
-                        *(uint2*)(p.ya + off[u] * p.ldya + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    }
+                    if (p.ya)
+                        *(uint2*)(p.ya + off[u] * p.ldya + co) = make_uint2(pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)),
+                                                                            pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope)));
                 }
             }
         }

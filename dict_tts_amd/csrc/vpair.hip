@@ -38,31 +38,33 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     const size_t wlane = (size_t)wc * 64 + lane;
     rb_preload<NT>(ring, p.w1 + wlane, NCT * 64);   // c1's first weights fly while the tile is staged
 
-    // ---- stage bf16(leaky_relu(x)) for rows [t0 - h2 - h1, t0 - h2 + TT + h1) ; zero outside the utterance
+    // ---- stage bf16(leaky_relu(x)) for rows [t0 - h2 - h1, t0 - h2 + TT + h1) ; zero outside the utterance.
+    // Buffer loads over the utterance [0, len) x C: an out-of-range row (t < 0 wraps to a huge unsigned offset,
+    // t >= len exceeds num_records) returns zeros = the reference's zero padding, with no per-access compare; a thread
+    // keeps its column and walks rows in steps of 8, so each access costs one v_add for its address.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const float* xu = p.x + brow * C;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, len * C * 4, 0x00020000);
+    constexpr int RSTEP = 256 / F4;                 // rows between two accesses of a thread (8)
+    const int c4 = tid % F4, r0 = tid / F4;
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
     if (!(p.dbg & 4)) {
-        constexpr int U = 12;   // 2 batches for k=11: each batch exposes one HBM latency
-        const int total = arows * F4;
-        for (int base = tid; base < total; base += 256 * U) {
-            f32x4 v[U];
+        constexpr int U = 12;                       // independent loads in flight per thread and batch
+        const int nk = (arows + RSTEP - 1) / RSTEP;
+        const int voff0 = ((a0 + r0) * C + c4 * 4) * 4;
+        char* lrow = smem + r0 * PITCH + c4 * 8;
+        for (int kb = 0; kb < nk; kb += U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff0 + (kb + u) * (RSTEP * C * 4), 0, 0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256;
-                const int r = idx / F4, c4 = idx % F4;
-                const int t = a0 + r;
-                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (idx < total && t >= 0 && t < len) v[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256;
-                if (idx >= total) continue;
-                const int r = idx / F4, c4 = idx % F4;
-                unsigned h[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = rf2bf(fmaxf(v[u][e], v[u][e] * 0.1f));
-                *(uint2*)(smem + r * PITCH + c4 * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (kb + u >= nk) continue;
+                const f32x4 f = __builtin_bit_cast(f32x4, v[u]);
+                *(uint2*)(lrow + (kb + u) * (RSTEP * PITCH)) =
+                    make_uint2(pack2bf(lrelu(f[0], 0.1f), lrelu(f[1], 0.1f)), pack2bf(lrelu(f[2], 0.1f), lrelu(f[3], 0.1f)));
             }
         }
     }
@@ -94,13 +96,8 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
         const bool inb = t >= 0 && t < len;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = acc[m][0][4 * q + e];
-                h[e] = rf2bf(fmaxf(a, a * 0.1f));
-            }
-            uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            uint2 pk = make_uint2(pack2bf(lrelu(acc[m][0][4 * q], 0.1f), lrelu(acc[m][0][4 * q + 1], 0.1f)),
+                                  pack2bf(lrelu(acc[m][0][4 * q + 2], 0.1f), lrelu(acc[m][0][4 * q + 3], 0.1f)));
             if (!inb) pk = make_uint2(0, 0);
             *(uint2*)(smem + r * PITCH + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
         }
@@ -121,21 +118,24 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
         return;
     }
     // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
-    // The global reads of slab m+1 are issued before slab m is processed (one exposed latency, not four).
+    // Buffer loads / stores again: rows >= len are dropped by the range check, the garbage rows o >= TTe of the last
+    // slab are sent out of range explicitly.  The reads of slab m+1 are issued before slab m is processed.
     constexpr int PER = 32 * F4 / 256;
-    f32x4 xin[2][PER], sold[2][PER];
-    auto fetch = [&](int m, f32x4 (&xi)[PER], f32x4 (&so)[PER]) {
+    float* yu = p.y + brow * C;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, len * C * 4, 0x00020000);
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ya ? p.ya + brow * C : (unsigned short*)yu), 0, len * C * 2, 0x00020000);
+    const int eoff0 = ((t0 + r0) * C + c4 * 4) * 4;
+    auto eoff = [&](int m, int u) {                 // byte offset of (slab m, access u) or out of range
+        const int o = m * 32 + u * RSTEP + r0;
+        return o < TTe ? eoff0 + (m * 32 + u * RSTEP) * (C * 4) : (int)0x80000000;
+    };
+    u32x4 xin[2][PER], sold[2][PER];
+    auto fetch = [&](int m, u32x4 (&xi)[PER], u32x4 (&so)[PER]) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int idx = tid + u * 256;
-            const int rl = idx / F4, c4 = idx % F4;
-            const int o = m * 32 + rl, t = t0 + o;
-            xi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            so[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (o < TTe && t < len) {
-                xi[u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
-                if (p.mode >= 2) so[u] = *(const f32x4*)(p.y + (brow + t) * C + c4 * 4);
-            }
+            const int off = eoff(m, u);
+            xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            if (p.mode >= 2) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
         }
     };
     fetch(0, xin[0], sold[0]);
@@ -153,23 +153,18 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int idx = tid + u * 256;
-            const int rl = idx / F4, c4 = idx % F4;
-            const int oo = m * 32 + rl, t = t0 + oo;
-            if (!(oo < TTe && t < len)) continue;
-            const long long off = (brow + t) * C + c4 * 4;
-            f32x4 o = *(const f32x4*)(smem + rl * EP + c4 * 16) + xin[m & 1][u];   // x = xt + x
-            if (p.mode >= 2) o += sold[m & 1][u];                                   // xs += x
+            const int off = eoff(m, u);
+            f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + __builtin_bit_cast(f32x4, xin[m & 1][u]);   // x = xt + x
+            if (p.mode >= 2) o += __builtin_bit_cast(f32x4, sold[m & 1][u]);                                                 // xs += x
             if (p.mode == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
-            *(f32x4*)(p.y + off) = o;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, off, 0, 0);
             if (p.mode == 3 && p.ya) {
-                unsigned h[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = rf2bf(o[e] > 0.f ? o[e] : o[e] * p.slope);
-                *(uint2*)(p.ya + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, 0);
             }
         }
     }
@@ -183,7 +178,7 @@ hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = 128 - 2 * h2;
     // staged rows + one spare tap for the activation prefetch; the xt phase needs 128 + (K-1) + 1 rows, the epilogue 32 fp32 rows
-    size_t rows = (size_t)128 + 2 * h1 + p.dil + 1;
+    size_t rows = (size_t)128 + 2 * h1 + p.dil + 1 + 8;   // + 8: the staging loop rounds the row count up to its step
     if (rows < (size_t)128 + p.K + 1) rows = 128 + p.K + 1;
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
