@@ -48,44 +48,90 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
 // ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
 // activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
 // of guard rows, so the prefetches past the last step need no clamping.
-template <int MT, int NT, int NKG, int PITCH>
-__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
-                                            int S, int dilP, int kg_stride_unused) {
-    constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
+// One group of 4 k-steps of the contraction (see rb_contract).  CINIT: the very first MFMA of every accumulator tile
+// takes its C operand from cinit[n] (the bias pattern of this lane's 16 channel slots, identical for every row tile), so
+// the accumulators need no initialisation pass at all.
+template <int MT, int NT, int NKG, int PITCH, bool CINIT>
+__device__ __forceinline__ void rb_group(f32x16 (&acc)[MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[2][MT],
+                                         const char* act, const uint4* wpf, int xb, int dilP, int g) {
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
     constexpr int KGS = (NKG / 2) * 64;               // uint4 elements between consecutive steps (= NCT * 64, NCT = NKG / 2)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
+        {   // activation fragments of step u+1
+            int off;
+            if constexpr (NKG >= 4) {
+                const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
+                off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
+            } else {
+                const int un = u + 1;                        // step within the group of TU taps
+                off = xb + (un / NKG) * dilP + (un % NKG) * 32;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (CINIT) {
+                    if (u == 0) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
+                                                                            cinit[n], 0, 0, 0);
+                        continue;
+                    }
+                }
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
+                                                                    acc[m][n], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc (+)= W * act over all taps.  Steps are processed 4 at a time (= TU taps); inside a group every LDS / global
+// offset is a compile-time immediate off two bases that advance once per group, so the loop body is MFMAs,
+// ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
+// activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
+// of guard rows, so the prefetches past the last step need no clamping.  CINIT: acc = cinit + W * act (acc not read).
+template <int MT, int NT, int NKG, int PITCH, bool CINIT = false>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
+                                            int S, int dilP, int kg_stride_unused, const f32x16 (*cinit)[NT] = nullptr) {
+    constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
+    constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
+    constexpr int KGS = (NKG / 2) * 64;
     uint4 xa[2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
     const uint4* wpf = w + 3 * KGS;                   // prefetch pointer, 3 steps ahead
     int xb = xrow0;                                   // LDS byte offset of (tap of this group, kg 0)
     int g = 0;
-    for (int s0 = 0; s0 < S; s0 += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
-            {   // activation fragments of step u+1
-                int off;
-                if constexpr (NKG >= 4) {
-                    const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
-                    off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
-                } else {
-                    const int un = u + 1;                        // step within the group of TU taps
-                    off = xb + (un / NKG) * dilP + (un % NKG) * 32;
+    int s0 = 0;
+    if constexpr (CINIT) {
+        if (S > 0) {
+            rb_group<MT, NT, NKG, PITCH, true>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
+            s0 = 4;
+            wpf += 4 * KGS;
+            if constexpr (NKG >= 4) {
+                if (++g == GPT) {
+                    g = 0;
+                    xb += dilP;
                 }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+            } else {
+                xb += TU * dilP;
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {   // ablation path (no contraction): acc = cinit
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
-                                                                        acc[m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int n = 0; n < NT; ++n) acc[m][n] = (*cinit)[n];
         }
+    }
+    for (; s0 < S; s0 += 4) {
+        const f32x16(&dummy)[NT] = *(const f32x16(*)[NT])acc[0];
+        rb_group<MT, NT, NKG, PITCH, false>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
         wpf += 4 * KGS;
         if constexpr (NKG >= 4) {
             if (++g == GPT) {
@@ -97,6 +143,5 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)
         }
     }
 }
-
 
 } // namespace dtts

@@ -126,18 +126,17 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
     f32x16 acc[MT][NT];
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
-        // conv1: the accumulator starts at the bias (no separate bias pass)
+        // conv1: the first MFMA of every tile takes the bias pattern as its C operand (no accumulator init pass)
+        f32x16 cinit[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][n][4 * q + e] = bb[n][q][e];
+                for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
         load_bias(bb, p.b2[it]);       // lands while conv1 runs
         const int d = p.dil[it];
-        rb_contract<MT, NT, NKG, PITCH>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride);
+        rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, p.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
         write_act(acc);                // xt (bf16, activated) overwrites it

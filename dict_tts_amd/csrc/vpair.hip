@@ -76,16 +76,15 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
 
     // ---- c1: xt rows r = 0..127  <->  global t0 - h2 + r ; reads staged rows r + tap * d
     f32x16 acc[MT][NT];
+    f32x16 cinit[NT];   // bias pattern of this lane's 16 channel slots: the C operand of every tile's first MFMA
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m][0][4 * q + e] = bb[q][e];
+        for (int e = 0; e < 4; ++e) cinit[0][4 * q + e] = bb[q][e];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b2 + wc * 32 + 8 * q + 4 * (lane >> 5));
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
-    rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0);
+    rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
     __syncthreads();   // every wave is done reading the x tile
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
@@ -105,12 +104,10 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     __syncthreads();
     // ---- c2: output rows o = 0..127 <-> global t0 + o (valid for o < TTe) ; reads xt rows o + tap
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m][0][4 * q + e] = bb[q][e];
-    rb_contract<MT, NT, NKG, PITCH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0);
+        for (int e = 0; e < 4; ++e) cinit[0][4 * q + e] = bb[q][e];
+    rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
     if (p.dbg & 2) {
