@@ -46,31 +46,32 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // ---- load the fp32 residual stream into accumulator layout (coalesced global -> LDS -> fragments).  All
-    // MT*PER 16 B loads of a thread are issued before the first LDS round trip: one exposed HBM latency per tile.
+    // ---- load the fp32 residual stream into accumulator layout (coalesced global -> LDS -> fragments).  Buffer loads
+    // over the utterance [0, len) x C return zeros for rows outside it (t < 0 wraps to a huge unsigned offset), which is
+    // exactly the zero padding needed, and cost one v_add per access.  All MT*PER 16 B loads of a thread are issued
+    // before the first LDS round trip: one exposed HBM latency per tile.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int PER = SROWS * F4 / THREADS;
-    static_assert(SROWS * F4 % THREADS == 0, "staging pass must divide evenly");
+    static_assert(SROWS * F4 % THREADS == 0 && THREADS / F4 == 32, "one staging pass = 32 rows per thread-row group");
+    const int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, 32)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + brow * C), 0, len * C * 4, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
+    const int goff0 = ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
     f32x16 xr[MT][NT];
     {
-        f32x4 ld[MT][PER];
+        u32x4 ld[MT][PER];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                const int idx = tid + u * THREADS;
-                const int rl = idx / F4, c4 = idx % F4;
-                const int t = base_t + ((rl >> 5) * MT + m) * 32 + (rl & 31);
-                ld[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (t >= 0 && t < len && !(p.dbg & 4)) ld[m][u] = *(const f32x4*)(p.x + (brow + t) * C + c4 * 4);
+                ld[m][u] = u32x4{0u, 0u, 0u, 0u};
+                if (!(p.dbg & 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff0 + (u * MT + m) * (32 * C * 4), 0, 0);
             }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             if (m) __syncthreads();
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int idx = tid + u * THREADS;
-                *(f32x4*)(stage + (idx / F4) * EP + (idx % F4) * 16) = ld[m][u];
-            }
+            for (int u = 0; u < PER; ++u) *(u32x4*)(stage + (r0 + 32 * u) * EP + c4 * 16) = ld[m][u];
             __syncthreads();
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
                     uint2 pk = make_uint2(pack2bf(lrelu(v[m][n][4 * q], 0.1f), lrelu(v[m][n][4 * q + 1], 0.1f)),
                                           pack2bf(lrelu(v[m][n][4 * q + 2], 0.1f), lrelu(v[m][n][4 * q + 3], 0.1f)));
-                    if (!inb) pk = make_uint2(0, 0);
+                    if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
         }
@@ -165,18 +166,21 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         return;
     }
     // ---- epilogue: rows [H, H+TT) of the tile leave as whole rows through the fp32 staging buffer; the old
-    // accumulator values (xs += ...) of all MT passes are fetched up front
-    f32x4 sold[MT][PER];
+    // accumulator values (xs += ...) of all MT passes are fetched up front.  Buffer ops: rows >= len are dropped by the
+    // range check, halo rows are sent out of range explicitly.
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Sa ? p.Sa + brow * C : (unsigned short*)(p.S + brow * C)), 0,
+                                                        len * C * 2, 0x00020000);
+    auto eoff = [&](int m, int u) {
+        const int row = (u * MT + m) * 32 + r0;
+        return (row >= H && row < H + TT) ? goff0 + (u * MT + m) * (32 * C * 4) : (int)0x80000000;
+    };
+    u32x4 sold[MT][PER];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int idx = tid + u * THREADS;
-            const int rl = idx / F4, c4 = idx % F4;
-            const int row = ((rl >> 5) * MT + m) * 32 + (rl & 31);
-            const int t = base_t + row;
-            sold[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.mode >= 1 && row >= H && row < H + TT && t < len) sold[m][u] = *(const f32x4*)(p.S + (brow + t) * C + c4 * 4);
+            sold[m][u] = u32x4{0u, 0u, 0u, 0u};
+            if (p.mode >= 1) sold[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0);
         }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -193,22 +197,18 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int idx = tid + u * THREADS;
-            const int rl = idx / F4, c4 = idx % F4;
-            const int row = ((rl >> 5) * MT + m) * 32 + (rl & 31);
-            const int t = base_t + row;
-            if (row < H || row >= H + TT || t >= len) continue;
-            f32x4 o = *(const f32x4*)(stage + rl * EP + c4 * 16);
-            float* dst = p.S + (brow + t) * C + c4 * 4;
-            o += sold[m][u];                             // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
+            const int off = eoff(m, u);
+            f32x4 o = *(const f32x4*)(stage + (r0 + 32 * u) * EP + c4 * 16);
+            o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
             if (p.mode == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
-            *(f32x4*)dst = o;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, 0);
             if (p.mode == 2 && p.Sa) {
-                *(uint2*)(p.Sa + (brow + t) * C + c4 * 4) =
-                    make_uint2(pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope)));
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, 0);
             }
         }
     }
