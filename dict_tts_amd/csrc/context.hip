@@ -652,13 +652,14 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
 // leaky_relu copy the next convolution consumes (written by the producer's epilogue).
 namespace {
 
-__global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int T, int n_stage, const int* mult) {
+struct StageMult { int m[9]; };  // cumulative upsampling factor per stage, passed by value (no H2D copy on the stream)
+__global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int T, int n_stage, StageMult mult) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * n_stage) return;
     const int sidx = i / B, b = i % B;
     int l = lens ? lens[b] : T;
     l = l < 0 ? 0 : (l > T ? T : l);
-    out[i] = l * mult[sidx];
+    out[i] = l * mult.m[sidx];
 }
 
 VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* lens, int B, int T) {
@@ -715,11 +716,10 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
     int* mult_d = A.alloc<int>(nup + 1);
     if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
     {
-        int mult[9];
-        mult[0] = 1;
-        for (int i = 0; i < nup; ++i) mult[i + 1] = mult[i] * c.upsample_rates[i];
-        HIPCHK(hipMemcpyAsync(mult_d, mult, sizeof(int) * (nup + 1), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(scale_lens_kernel2, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult_d);
+        StageMult mult;
+        mult.m[0] = 1;
+        for (int i = 0; i < nup; ++i) mult.m[i + 1] = mult.m[i] * c.upsample_rates[i];
+        hipLaunchKernelGGL(scale_lens_kernel2, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult);
     }
     HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
     const int TV = DTTS_TIMER_VOC_CONV;
@@ -975,13 +975,13 @@ int dtts_finalize_weights(dtts_handle h, int parts) {
 
 int dtts_hifigan_hop(dtts_handle h) { return h ? h->hop : 0; }
 
-__global__ void scale_lens_kernel(const int32_t* lens, int32_t* out, int B, int T, int n_stage, const int* mult) {
+__global__ void scale_lens_kernel(const int32_t* lens, int32_t* out, int B, int T, int n_stage, StageMult mult) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * n_stage) return;
     const int sidx = i / B, b = i % B;
     int l = lens ? lens[b] : T;
     l = l < 0 ? 0 : (l > T ? T : l);
-    out[i] = l * mult[sidx];
+    out[i] = l * mult.m[sidx];
 }
 
 int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, int B, int T, float* wav, dtts_stream stream) {
@@ -1012,11 +1012,10 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     int* mult_d = h->a_voc.alloc<int>(nup + 1);
     if (!bufX || !bufR || !bufT || !bufS || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
     {
-        int mult[9];
-        mult[0] = 1;
-        for (int i = 0; i < nup; ++i) mult[i + 1] = mult[i] * c.upsample_rates[i];
-        HIPCHK(hipMemcpyAsync(mult_d, mult, sizeof(int) * (nup + 1), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(scale_lens_kernel, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult_d);
+        StageMult mult;
+        mult.m[0] = 1;
+        for (int i = 0; i < nup; ++i) mult.m[i + 1] = mult.m[i] * c.upsample_rates[i];
+        hipLaunchKernelGGL(scale_lens_kernel, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult);
     }
     const int TV = DTTS_TIMER_VOC_CONV;
     // conv_pre: mel [B,T,80] -> S [B,T,512]
