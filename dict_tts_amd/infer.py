@@ -38,9 +38,7 @@ def wav_to_int16(wav, norm=False):
 def infer_batch(model, vocoder, batch, z_p=None):
     """batch: dict of tensors as DictTTSDataset.collater produces (word_tokens, keys, values, key_map, pinyin,
     pinyin_map, pron_modified).  Returns (outputs dict, list of float32 waveforms, one per utterance)."""
-    out = model((batch["word_tokens"], batch.get("txt_tokens")), batch.get("pron_modified"), (None, None, None),
-                batch.get("ph2word"), None,
-                (batch["keys"], batch["values"], batch["key_map"], batch["pinyin"], batch["pinyin_map"]), infer=True, z_p=z_p)
+    out = _model_forward(model, batch, z_p)
     lens = out["mel_lens"]
     wav = vocoder.forward_batch(out["mel_out"], lens)
     hop = vocoder.hop
@@ -49,14 +47,61 @@ def infer_batch(model, vocoder, batch, z_p=None):
     return out, [wav_h[i, : lens_h[i] * hop] for i in range(len(lens_h))]
 
 
-def run_inference(model, vocoder, batches, gen_dir, pinyin_encoder, sample_rate=22050, save_wavs=True, out_wav_norm=False):
+def _model_forward(model, batch, z_p):
+    return model((batch["word_tokens"], batch.get("txt_tokens")), batch.get("pron_modified"), (None, None, None),
+                 batch.get("ph2word"), None,
+                 (batch["keys"], batch["values"], batch["key_map"], batch["pinyin"], batch["pinyin_map"]), infer=True, z_p=z_p)
+
+
+def _iter_results(model, vocoder, batches, pipeline):
+    """yields (batch, outputs, waveforms) per batch.  pipeline=True: the vocoder of batch i runs on a second HIP stream
+    while text->mel of batch i+1 runs on the current one (the acoustic model's small kernels leave most CUs idle;
+    bench.py measures this arrangement), and batch i's device->host copies happen after batch i+1 has been enqueued."""
+    if not pipeline:
+        for batch in batches:
+            out, wavs = infer_batch(model, vocoder, batch, batch.get("z_p"))
+            yield batch, out, wavs
+        return
+    main = torch.cuda.current_stream()
+    voc_stream = torch.cuda.Stream()
+    hop = vocoder.hop
+
+    def finish(p):
+        batch, out, wav, done = p
+        done.synchronize()
+        with torch.cuda.stream(voc_stream):
+            wav_h = wav.cpu().numpy()
+        lens_h = out["mel_lens"].cpu().tolist()
+        return batch, out, [wav_h[i, : lens_h[i] * hop] for i in range(len(lens_h))]
+
+    pending = None
+    for batch in batches:
+        out = _model_forward(model, batch, batch.get("z_p"))
+        voc_stream.wait_stream(main)
+        with torch.cuda.stream(voc_stream):
+            wav = vocoder.forward_batch(out["mel_out"], out["mel_lens"])
+        out["mel_out"].record_stream(voc_stream)
+        out["mel_lens"].record_stream(voc_stream)
+        done = torch.cuda.Event()
+        done.record(voc_stream)
+        if pending is not None:
+            yield finish(pending)
+        pending = (batch, out, wav, done)
+    if pending is not None:
+        yield finish(pending)
+
+
+def run_inference(model, vocoder, batches, gen_dir, pinyin_encoder, sample_rate=22050, save_wavs=True, out_wav_norm=False,
+                  pipeline=None):
     """batches: iterable of dicts with the tensors above plus 'item_name' (list[str]) and 'text' (list[str]).
     pinyin_encoder: list mapping pinyin-token id -> string (``pinyin_encoder.pkl`` of the reference).
-    Writes <gen_dir>/wavs/*.wav and <gen_dir>/meta.csv; returns the meta rows."""
+    Writes <gen_dir>/wavs/*.wav and <gen_dir>/meta.csv; returns the meta rows.
+    pipeline: overlap the vocoder with the next batch's text->mel on two streams (default: on for the HIP model)."""
     os.makedirs(os.path.join(gen_dir, "wavs"), exist_ok=True)
     rows, results_id = [], 0
-    for batch in batches:
-        out, wavs = infer_batch(model, vocoder, batch, batch.get("z_p"))
+    if pipeline is None:
+        pipeline = hasattr(model, "ctx") and hasattr(vocoder, "ctx")
+    for batch, out, wavs in _iter_results(model, vocoder, batches, pipeline):
         pron_attn = out["pron_attn"].cpu()
         for i, wav in enumerate(wavs):
             item_name, text = batch["item_name"][i], batch["text"][i]
