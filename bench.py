@@ -223,6 +223,59 @@ def main():
     elapsed = time.perf_counter() - t0
     frames_rank = int(lens_acc.item())
     conv_ms, conv_launches = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
+    stages = None
+    if rank == 0:
+        # outside the timed region, nothing else on the GPU: per-stage rates and the rooflines SURVEY.md 8(d) names
+        # for the other two stages (S2PA: HBM-bound; mel decoder: fp32 MFMA), one stream, 3 repetitions
+        m.ctx.timer_enable(abi.TIMER_S2PA)
+        m.ctx.timer_reset()
+        ms_enc = ms_dec = ms_voc = 0.0
+        stream = torch.cuda.current_stream().cuda_stream
+        ptr = lambda t: t.data_ptr()
+        for _ in range(3):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            if args.dict_table:
+                T_m = m.ctx.text2mel_encode_ids(ptr(batch["word_tokens"]), ptr(batch["entry_ids"]), ptr(batch["pron_modified"]),
+                                                None, B, T_w, L_k, P_, stream)
+            else:
+                T_m = m.ctx.text2mel_encode(ptr(batch["word_tokens"]), ptr(batch["keys"]), ptr(batch["values"]),
+                                            ptr(batch["key_map"]), ptr(batch["pinyin"]), ptr(batch["pinyin_map"]),
+                                            ptr(batch["pron_modified"]), None, B, T_w, L_k, P_, stream)
+            ev[1].record()
+            z_i = z_all[:, :, : T_m // 4].contiguous()
+            mel_i = torch.empty(B, T_m, 80, device=dev)
+            m.ctx.text2mel_decode(z_i.data_ptr(), mel_i.data_ptr(), stream)
+            lens_i = torch.empty(B, dtype=torch.int32, device=dev)
+            m.ctx.fetch(abi.OUT_MEL_LENS, lens_i.data_ptr(), stream)
+            ev[2].record()
+            voc.forward_batch(mel_i, lens_i)
+            ev[3].record()
+            torch.cuda.synchronize()
+            ms_enc += ev[0].elapsed_time(ev[1]) / 3
+            ms_dec += ev[1].elapsed_time(ev[2]) / 3
+            ms_voc += ev[2].elapsed_time(ev[3]) / 3
+        s2pa_ms, s2pa_n = m.ctx.timer_read(abi.TIMER_S2PA)
+        fr = int(lens_i.sum().item())
+        if args.dict_table:
+            gloss_rows = None
+        else:
+            gloss_rows = int((batch["key_map"] != 0).sum().item())   # rows the softmax does not mask = rows that must be read
+        stages = {"isolated": True, "mel_frames_per_batch": fr,
+                  "text2mel": {"ms": ms_enc + ms_dec, "encode_ms": ms_enc, "decode_ms": ms_dec,
+                               "mel_frames_per_s": fr / ((ms_enc + ms_dec) * 1e-3)},
+                  "vocoder": {"ms": ms_voc, "mel_frames_per_s": fr / (ms_voc * 1e-3)},
+                  "end_to_end_serial": {"ms": ms_enc + ms_dec + ms_voc, "mel_frames_per_s": fr / ((ms_enc + ms_dec + ms_voc) * 1e-3)},
+                  # A8-A10: 4,691,968 FLOP per (padded) mel frame, fp32 MFMA peak 157.3 TFLOP/s; launch-bound at this size
+                  "mel_decoder_roofline": {"bound": "mfma(f32)", "achieved": 4_691_968 * B * T_m / (ms_dec * 1e-3) / 1e12,
+                                           "peak": 157.3, "unit": "TFLOP/s",
+                                           "frac": 4_691_968 * B * T_m / (ms_dec * 1e-3) / 1e12 / 157.3}}
+        if gloss_rows is not None and s2pa_ms > 0:
+            gbs = 6144.0 * gloss_rows / (s2pa_ms / max(s2pa_n, 1) * 1e-3) / 1e9
+            stages["s2pa_roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                       "kernel": "dtts::s2pa_kernel", "avg_launch_ms": s2pa_ms / max(s2pa_n, 1),
+                                       "algorithmic_bytes": "6144 B x unmasked gloss rows (fp32 keys + values, 768 wide)",
+                                       "unmasked_gloss_rows": gloss_rows, "padded_gloss_rows": B * T_w * L_k}
     iso = None
     if pipelined and rank == 0:
         # outside the timed region: the same vocoder kernels on the last batch with nothing else on the GPU, so that
@@ -288,6 +341,8 @@ def main():
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "kernel_ms_per_step": conv_ms / max(args.steps, 1),
                          "algorithmic_flop_per_mel_frame": FLOP_PER_FRAME_VOCODER},
         }
+        if stages is not None:
+            out["stages"] = stages
         if iso is not None and iso[0] > 0:
             ia = FLOP_PER_FRAME_VOCODER * iso[2] / (iso[0] * 1e-3) / 1e12
             out["roofline"]["note"] = ("achieved/frac are measured inside the timed region, where these kernels share the CUs "

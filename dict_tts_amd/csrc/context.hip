@@ -1172,6 +1172,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         a.pron_modified = pron_modified;
         a.pinyin_emb = h->pinyin_emb;
         a.pm_max = pm_max;
+        a.lens = h->lens;
         a.wv = wv;
         a.dict_attn = h->dict_attn;
         a.pron_attn = h->pron_attn;

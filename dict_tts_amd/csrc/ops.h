@@ -38,6 +38,8 @@ struct S2paArgs {
     const int64_t* pron_modified; // [B*T_w] or null
     const float* pinyin_emb;      // [n_pinyin][H]
     const int* pm_max;            // device scalar: max(pinyin_map) over the batch
+    const int* lens;              // [B] words per utterance, or null: the caller zeroes context for t >= lens[b]
+                                  // (dict_encoder.py:140), so the value rows of those words are not streamed
     float* wv;                    // [B*T_w][D]
     float* dict_attn;             // [B][1][L_k][T_w]
     float* pron_attn;             // [B*T_w][P]

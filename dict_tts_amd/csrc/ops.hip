@@ -1,6 +1,8 @@
 // Non-GEMM kernels of the Dict-TTS path.  See ops.h for the contracts and the reference lines they follow.
 #include "ops.h"
 
+#include <cstdlib>
+
 namespace dtts {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -172,13 +174,17 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
 // ---------------------------------------------------------------------------------------------------------
 // S2PA dictionary attention: one block per word, gloss rows streamed once with 16 B/lane loads.
 constexpr int S2PA_LMAX = 1024, S2PA_DMAX4 = 3;  // D <= 768 (3 float4 per lane), L_k <= 1024
-__global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
+// S2PA_NW waves per word, each keeping S2PA_RU gloss rows (3 x 16 B per lane each) in flight
+template <int S2PA_NW, int S2PA_RU>
+__global__ __launch_bounds__(S2PA_NW * 64) void s2pa_kernel(const S2paArgs a) {
     __shared__ float lg[S2PA_LMAX];
     __shared__ float km[S2PA_LMAX];
-    __shared__ __attribute__((aligned(16))) float part[4][768];
-    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float part[S2PA_NW][768];
+    __shared__ float red[2 * S2PA_NW];
     __shared__ float sense[16];
     __shared__ float pw[64];
+    __shared__ int pid[64 + 4];
+    constexpr int NTHR = S2PA_NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;  // b * T_w + t
     const int b = row / a.T_w, t = row % a.T_w;
@@ -215,54 +221,86 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
         pin = a.pinyin + (long long)row * a.P;
         pmr = a.pinyin_map + (long long)row * a.P;
     }
-    for (int l = tid; l < L; l += 256) km[l] = l < Lrow ? kmr[l] : (special == -1 ? 1.f : 0.f);
+    // key_map row; every logit starts at its masked / zero-vector value, only rows that must be READ are listed
+    __shared__ unsigned short idx[S2PA_LMAX];
+    __shared__ int n_live;
+    for (int l = tid; l < L; l += NTHR) {
+        const float k = l < Lrow ? kmr[l] : (special == -1 ? 1.f : 0.f);
+        km[l] = k;
+        lg[l] = k == 0.f ? -1e9f : 0.f;   // key_map == 0: masked regardless of content; table-mode BOS / last row: zero gloss vector
+    }
     // the query, 12 floats per lane
     f32x4 q[S2PA_DMAX4];
     const f32x4* qp = (const f32x4*)(a.qk + (long long)row * a.D);
 #pragma unroll
     for (int c = 0; c < S2PA_DMAX4; ++c) q[c] = (lane + 64 * c < D4) ? qp[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    // logits (rows with key_map == 0 are masked regardless of their content: not read at all)
-    for (int l = wave; l < L; l += 4) {
-        if (km[l] == 0.f) {
-            if (lane == 0) lg[l] = -1e9f;
-            continue;
+    if (wave == 0) {   // ordered compaction of the unmasked rows (ballot prefix), so that the streaming loops below
+        int cnt = 0;   // run over dense work and can keep several rows in flight
+        for (int base = 0; base < Lrow; base += 64) {
+            const int l = base + lane;
+            const bool live = l < Lrow && km[l] != 0.f;
+            const unsigned long long m = __ballot(live);
+            if (live) idx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)l;
+            cnt += __popcll(m);
         }
-        if (l >= Lrow) {   // table mode, BOS / last row: zero gloss vector
-            if (lane == 0) lg[l] = 0.f;
-            continue;
-        }
-        const f32x4* kr = kb + (long long)l * D4;
-        float acc = 0.f;
+        if (cnt == 0)   // every row masked: all logits are -1e9, the softmax is uniform and every value row contributes
+            for (int l = lane; l < Lrow; l += 64) idx[l] = (unsigned short)l;
+        if (lane == 0) n_live = cnt;
+    }
+    __syncthreads();
+    const int n = n_live;
+    // a word past the end of its utterance: its weights are still returned (dict_attn), its context is zeroed by the
+    // caller whatever the values are, so nothing is read for it
+    const bool dead = a.lens && t >= a.lens[b];
+    const int n_val = dead ? 0 : (n ? n : Lrow);
+    // logits: a wave takes 4 listed rows at a time - 12 independent 16-byte loads per lane before the first reduction
+    constexpr int RU = S2PA_RU;
+    for (int i = wave * RU; i < n; i += S2PA_NW * RU) {
+        f32x4 k[RU][S2PA_DMAX4];
+        int lr[RU];
 #pragma unroll
-        for (int c = 0; c < S2PA_DMAX4; ++c)
-            if (lane + 64 * c < D4) {
-                const f32x4 k = kr[lane + 64 * c];
-                acc += k[0] * q[c][0] + k[1] * q[c][1] + k[2] * q[c][2] + k[3] * q[c][3];
-            }
-        acc = wave_sum(acc);
-        if (lane == 0) lg[l] = acc;
+        for (int j = 0; j < RU; ++j) {
+            lr[j] = idx[min(i + j, n - 1)];
+            const f32x4* kr = kb + (long long)lr[j] * D4;
+#pragma unroll
+            for (int c = 0; c < S2PA_DMAX4; ++c)
+                k[j][c] = (lane + 64 * c < D4) ? kr[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < S2PA_DMAX4; ++c)
+                if (lane + 64 * c < D4) acc += k[j][c][0] * q[c][0] + k[j][c][1] * q[c][1] + k[j][c][2] * q[c][2] + k[j][c][3] * q[c][3];
+            acc = wave_sum(acc);
+            if (lane == 0 && i + j < n) lg[lr[j]] = acc;
+        }
     }
     __syncthreads();
     // softmax over l
     float mx = -3.0e38f;
-    for (int l = tid; l < L; l += 256) mx = fmaxf(mx, lg[l]);
+    for (int l = tid; l < L; l += NTHR) mx = fmaxf(mx, lg[l]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < S2PA_NW; ++w) mx = fmaxf(mx, red[w]);
     float sm = 0.f;
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NTHR) {
         const float e = expf(lg[l] - mx);
         lg[l] = e;
         sm += e;
     }
     sm = wave_sum(sm);
-    if (lane == 0) red[4 + wave] = sm;
+    if (lane == 0) red[S2PA_NW + wave] = sm;
     __syncthreads();
-    sm = (red[4] + red[5]) + (red[6] + red[7]);
+    sm = 0.f;
+#pragma unroll
+    for (int w = 0; w < S2PA_NW; ++w) sm += red[S2PA_NW + w];   // fixed order: reproducible
     float* da = a.dict_attn + ((long long)b * L) * a.T_w + t;
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NTHR) {
         const float w = lg[l] / sm;
         lg[l] = w;
         da[(long long)l * a.T_w] = w;
@@ -272,13 +310,23 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
     f32x4 acc[S2PA_DMAX4];
 #pragma unroll
     for (int c = 0; c < S2PA_DMAX4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int l = wave; l < Lrow; l += 4) {   // rows >= Lrow are zero vectors (table mode) or do not exist
-        const float w = lg[l];
-        if (w == 0.f) continue;
-        const f32x4* vr = vb + (long long)l * D4;
+    // (masked rows have weight exactly 0 and rows >= Lrow are zero vectors: only the listed rows contribute)
+    for (int i = wave * RU; i < n_val; i += S2PA_NW * RU) {
+        f32x4 v[RU][S2PA_DMAX4];
+        float w[RU];
 #pragma unroll
-        for (int c = 0; c < S2PA_DMAX4; ++c)
-            if (lane + 64 * c < D4) acc[c] += vr[lane + 64 * c] * w;
+        for (int j = 0; j < RU; ++j) {
+            const int l = idx[min(i + j, n_val - 1)];
+            w[j] = i + j < n_val ? lg[l] : 0.f;
+            const f32x4* vr = vb + (long long)l * D4;
+#pragma unroll
+            for (int c = 0; c < S2PA_DMAX4; ++c)
+                v[j][c] = (lane + 64 * c < D4) ? vr[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j)
+#pragma unroll
+            for (int c = 0; c < S2PA_DMAX4; ++c) acc[c] += v[j][c] * w[j];
     }
 #pragma unroll
     for (int c = 0; c < S2PA_DMAX4; ++c)
@@ -291,7 +339,12 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
         sense[tid] = s;
     }
     __syncthreads();
-    for (int c = tid; c < a.D; c += 256) a.wv[(long long)row * a.D + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    for (int c = tid; c < a.D; c += NTHR) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < S2PA_NW; ++w) sum += part[w][c];
+        a.wv[(long long)row * a.D + c] = sum;
+    }
     // pronunciation weights
     if (tid < a.P && tid < 64) {
         const long long pm = tid < Prow ? pmr[tid] : (special == -1 ? 1 : 0);
@@ -307,21 +360,36 @@ __global__ __launch_bounds__(256) void s2pa_kernel(const S2paArgs a) {
         }
         pw[tid] = w;
         a.pron_attn[(long long)row * a.P + tid] = w;
+        long long id = tid < Prow ? pin[tid] : 0;
+        if (id < 0 || id >= a.n_pinyin) id = 0;
+        pid[tid] = (int)id;
     }
     __syncthreads();
-    for (int c = tid; c < a.H; c += 256) {
+    for (int c = tid; c < a.H; c += NTHR) {
         float s = 0.f;
-        for (int p = 0; p < a.P; ++p) {
-            long long id = p < Prow ? pin[p] : 0;
-            if (id < 0 || id >= a.n_pinyin) id = 0;
-            s += pw[p] * a.pinyin_emb[id * a.H + c];
+        for (int p0 = 0; p0 < a.P; p0 += 4) {   // 4 embedding rows in flight, summed in p order
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = p0 + j < a.P ? a.pinyin_emb[(long long)pid[p0 + j] * a.H + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < a.P) s += pw[p0 + j] * e[j];
         }
         a.pron[(long long)row * a.H + c] = s;
     }
 }
 hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
     if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(s2pa_kernel, dim3(a.B * a.T_w), dim3(256), 0, s, a);
+    static const int cfg = getenv("DTTS_S2PA_CFG") ? atoi(getenv("DTTS_S2PA_CFG")) : 0;   // tuning switch
+    const dim3 grid(a.B * a.T_w);
+    switch (cfg) {
+    case 2: hipLaunchKernelGGL((s2pa_kernel<4, 8>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((s2pa_kernel<8, 4>), grid, dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((s2pa_kernel<16, 2>), grid, dim3(1024), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((s2pa_kernel<16, 4>), grid, dim3(1024), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((s2pa_kernel<8, 8>), grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((s2pa_kernel<4, 4>), grid, dim3(256), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 
