@@ -19,7 +19,7 @@ TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
 EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
-           "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
+           "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
 
 
 class DttsConfig(C.Structure):
@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.dtts_hifigan_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.dtts_length_regulate.argtypes = [vp, vp, vp, i32, i32, vp, i32, C.POINTER(C.c_int32), vp]
     lib.dtts_hifigan_hop.argtypes = [vp]
+    lib.dtts_wav_to_int16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dtts_timer_enable.argtypes = [vp, i32]
     lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dtts_timer_reset.argtypes = [vp]
@@ -171,6 +172,9 @@ class Context:
 
     def hifigan_forward(self, mel, lens, B, T, wav, stream):
         self._chk(self.lib.dtts_hifigan_forward(self.h, mel, lens or None, B, T, wav, stream), "dtts_hifigan_forward")
+
+    def wav_to_int16(self, wav, lens, B, T, norm, out, stream):
+        self._chk(self.lib.dtts_wav_to_int16(self.h, wav, lens or None, B, T, int(bool(norm)), out, stream), "dtts_wav_to_int16")
 
     def timer_enable(self, which):
         self._chk(self.lib.dtts_timer_enable(self.h, which), "dtts_timer_enable")

@@ -122,6 +122,8 @@ struct dtts_ctx {
     int hop = 1;
     // ---- workspaces and per-call state
     Arena a_enc, a_dec, a_voc;
+    unsigned* amax_bits = nullptr;  // dtts_wav_to_int16 scratch
+    int amax_cap = 0;
     int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
     bool encoded = false;
     float *weo = nullptr, *dur = nullptr, *pron_attn = nullptr, *dict_attn = nullptr, *context = nullptr, *x_mask = nullptr;
@@ -935,6 +937,7 @@ void dtts_destroy(dtts_handle h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->amax_bits) (void)hipFree(h->amax_bits);
     h->a_enc.release();
     h->a_dec.release();
     h->a_voc.release();
@@ -974,6 +977,24 @@ int dtts_finalize_weights(dtts_handle h, int parts) {
 }
 
 int dtts_hifigan_hop(dtts_handle h) { return h ? h->hop : 0; }
+
+int dtts_wav_to_int16(dtts_handle h, const float* wav, const int32_t* lens, int B, int T, int norm, int16_t* out, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->vocoder_ready) return fail(h, DTTS_E_STATE, "vocoder weights not finalized");
+    if (!wav || !out || B <= 0 || T <= 0) return fail(h, DTTS_E_INVAL, "dtts_wav_to_int16: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->amax_bits || h->amax_cap < B) {   // tiny persistent scratch, grown outside the steady state
+        if (h->amax_bits) {
+            HIPCHK(hipDeviceSynchronize());
+            (void)hipFree(h->amax_bits);
+            h->amax_bits = nullptr;
+        }
+        HIPCHK(hipMalloc((void**)&h->amax_bits, sizeof(unsigned) * std::max(B, 256)));
+        h->amax_cap = std::max(B, 256);
+    }
+    LAUNCH(wav_to_int16_launch(wav, lens, h->hop, B, (long long)T * h->hop, norm, h->amax_bits, out, s));
+    return DTTS_OK;
+}
 
 __global__ void scale_lens_kernel(const int32_t* lens, int32_t* out, int B, int T, int n_stage, StageMult mult) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -88,6 +88,12 @@ hipError_t mel2word_copy_launch(const int64_t* src, int64_t* dst, int* total, in
 hipError_t expand_launch(const float* weo, const int64_t* m2w, float* x, float* x_mask, int B, int T_w, int T_mel, int C,
                          hipStream_t s);
 
+// save_wav's sample conversion on the device (utils/audio.py:11-16): per utterance b over its n_b = lens[b] * hop valid
+// samples: norm -> w / max|w|; w * 32767 in fp32; truncating cast to int16.  Samples past n_b are written as 0.
+// amax_bits [B] u32 scratch (only used when norm).
+hipError_t wav_to_int16_launch(const float* wav, const int* lens, int hop, int B, long long N, int norm, unsigned* amax_bits,
+                               int16_t* out, hipStream_t s);
+
 // [B][C][T] -> [B][T][C] transpose (z_p arrives channels-first as the reference samples it)
 hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s);
 

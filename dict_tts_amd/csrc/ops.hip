@@ -1,6 +1,7 @@
 // Non-GEMM kernels of the Dict-TTS path.  See ops.h for the contracts and the reference lines they follow.
 #include "ops.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace dtts {
@@ -390,6 +391,43 @@ hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
     case 6: hipLaunchKernelGGL((s2pa_kernel<8, 8>), grid, dim3(512), 0, s, a); break;
     default: hipLaunchKernelGGL((s2pa_kernel<4, 4>), grid, dim3(256), 0, s, a); break;
     }
+    return hipGetLastError();
+}
+
+// ---- waveform -> int16 (utils/audio.py:11-16)
+__global__ void wav_absmax_kernel(const float* wav, const int* lens, int hop, long long N, unsigned* amax_bits) {
+    const int b = blockIdx.y;
+    const long long n = lens ? min((long long)max(lens[b], 0) * hop, N) : N;
+    const float* w = wav + (long long)b * N;
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits + b, __float_as_uint(m));  // non-negative floats order as their bits
+}
+__global__ void wav_to_int16_kernel(const float* wav, const int* lens, int hop, long long N, int norm, const unsigned* amax_bits,
+                                    int16_t* out) {
+    const int b = blockIdx.y;
+    const long long n = lens ? min((long long)max(lens[b], 0) * hop, N) : N;
+    const float* w = wav + (long long)b * N;
+    int16_t* o = out + (long long)b * N;
+    const float m = norm ? __uint_as_float(amax_bits[b]) : 1.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        float v = i < n ? w[i] : 0.f;
+        if (norm) v = v / m;               // wav / np.abs(wav).max(): IEEE fp32 division, as numpy
+        v = v * 32767.f;                    // wav *= 32767 (fp32)
+        o[i] = (int16_t)(int)v;             // astype(np.int16): truncation toward zero (|v| <= 32767 on this path)
+    }
+}
+hipError_t wav_to_int16_launch(const float* wav, const int* lens, int hop, int B, long long N, int norm, unsigned* amax_bits,
+                               int16_t* out, hipStream_t s) {
+    const int bx = (int)std::min<long long>((N + 256 * 8 - 1) / (256 * 8), 1024);
+    if (norm) {
+        hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned) * B, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wav_absmax_kernel, dim3(bx, B), dim3(256), 0, s, wav, lens, hop, N, amax_bits);
+    }
+    hipLaunchKernelGGL(wav_to_int16_kernel, dim3(bx, B), dim3(256), 0, s, wav, lens, hop, N, norm, amax_bits, out);
     return hipGetLastError();
 }
 

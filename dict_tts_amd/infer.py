@@ -53,7 +53,7 @@ def _model_forward(model, batch, z_p):
                  (batch["keys"], batch["values"], batch["key_map"], batch["pinyin"], batch["pinyin_map"]), infer=True, z_p=z_p)
 
 
-def _iter_results(model, vocoder, batches, pipeline):
+def _iter_results(model, vocoder, batches, pipeline, out_wav_norm=False):
     """yields (batch, outputs, waveforms) per batch.  pipeline=True: the vocoder of batch i runs on a second HIP stream
     while text->mel of batch i+1 runs on the current one (the acoustic model's small kernels leave most CUs idle;
     bench.py measures this arrangement), and batch i's device->host copies happen after batch i+1 has been enqueued."""
@@ -64,13 +64,14 @@ def _iter_results(model, vocoder, batches, pipeline):
         return
     main = torch.cuda.current_stream()
     voc_stream = torch.cuda.Stream()
+    int16_on_device = hasattr(vocoder, "to_int16")
     hop = vocoder.hop
 
     def finish(p):
         batch, out, wav, done = p
         done.synchronize()
         with torch.cuda.stream(voc_stream):
-            wav_h = wav.cpu().numpy()
+            wav_h = wav.cpu().numpy()          # int16 when the vocoder converts on the device (half the copy)
         lens_h = out["mel_lens"].cpu().tolist()
         return batch, out, [wav_h[i, : lens_h[i] * hop] for i in range(len(lens_h))]
 
@@ -80,6 +81,8 @@ def _iter_results(model, vocoder, batches, pipeline):
         voc_stream.wait_stream(main)
         with torch.cuda.stream(voc_stream):
             wav = vocoder.forward_batch(out["mel_out"], out["mel_lens"])
+            if int16_on_device:
+                wav = vocoder.to_int16(wav, out["mel_lens"], norm=out_wav_norm)
         out["mel_out"].record_stream(voc_stream)
         out["mel_lens"].record_stream(voc_stream)
         done = torch.cuda.Event()
@@ -101,7 +104,7 @@ def run_inference(model, vocoder, batches, gen_dir, pinyin_encoder, sample_rate=
     rows, results_id = [], 0
     if pipeline is None:
         pipeline = hasattr(model, "ctx") and hasattr(vocoder, "ctx")
-    for batch, out, wavs in _iter_results(model, vocoder, batches, pipeline):
+    for batch, out, wavs in _iter_results(model, vocoder, batches, pipeline, out_wav_norm):
         pron_attn = out["pron_attn"].cpu()
         for i, wav in enumerate(wavs):
             item_name, text = batch["item_name"][i], batch["text"][i]
@@ -109,7 +112,8 @@ def run_inference(model, vocoder, batches, gen_dir, pinyin_encoder, sample_rate=
             ids = decode_pinyin_ids(pron_attn[i, :n_words], torch.as_tensor(batch["pinyin"][i][:n_words]))
             base_fn = base_filename(results_id, item_name, text)
             if save_wavs:
-                wavfile.write(os.path.join(gen_dir, "wavs", (base_fn % "P") + ".wav"), sample_rate, wav_to_int16(wav, out_wav_norm))
+                pcm = wav if wav.dtype == np.int16 else wav_to_int16(wav, out_wav_norm)   # int16: converted on the device
+                wavfile.write(os.path.join(gen_dir, "wavs", (base_fn % "P") + ".wav"), sample_rate, pcm)
             rows.append({"item_name": item_name, "text": text.replace(",", "，").replace(".", "。"),
                          "pinyin_tokens": " ".join(pinyin_encoder[j] for j in ids),
                          "wav_fn_pred": base_fn % "P", "wav_fn_gt": base_fn % "G"})

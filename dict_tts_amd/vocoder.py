@@ -96,6 +96,19 @@ class HifiGAN:
                                  torch.cuda.current_stream().cuda_stream)
         return wav
 
+    def to_int16(self, wav, lens=None, norm=False):
+        """save_wav's sample conversion (utils/audio.py:11-16) on the device: wav [B, T*hop] float32 cuda tensor as
+        forward_batch returned it, lens [B] valid frames -> int16 cuda tensor [B, T*hop] (zeros past each utterance)"""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.shape[1] % self.hop == 0
+        wav = wav.contiguous()
+        B, N = wav.shape
+        out = torch.empty(B, N, dtype=torch.int16, device=wav.device)
+        if lens is not None:
+            lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
+        self.ctx.wav_to_int16(wav.data_ptr(), lens.data_ptr() if lens is not None else None, B, N // self.hop, norm,
+                              out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
+
     def spec2wav_batch(self, mels):
         """list of [T_i,80] arrays -> list of float32 arrays [T_i*hop]; each equals spec2wav(mel_i) of the reference"""
         lens = [int(np.asarray(m).shape[0]) for m in mels]

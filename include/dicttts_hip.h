@@ -175,6 +175,16 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* len
 int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
 
 /*
+ * Output side — replaces the sample conversion of save_wav (utils/audio.py:11-16; called from after_infer,
+ * tasks/tts/dict_tts.py:282-283) for a batch, on the device, so that the device->host copy is int16:
+ * wav [B, T*hop] f32 as dtts_hifigan_forward wrote it, lens [B] i32 valid frames (NULL = T for all);
+ * per utterance over its own lens[b]*hop samples: norm != 0 -> w / max|w| ; w * 32767 (fp32) ; truncating cast.
+ * out [B, T*hop] i16, samples past an utterance's end are 0.
+ */
+int dtts_wav_to_int16(dtts_handle h, const float* wav_dev, const int32_t* lens_dev, int B, int T, int norm, int16_t* out_dev,
+                      dtts_stream stream);
+
+/*
  * Instrumentation used by bench.py: accumulated device time (hipEvent pairs recorded on the caller's stream
  * around every launch of one kernel family) since the last reset.
  */

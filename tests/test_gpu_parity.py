@@ -350,3 +350,27 @@ def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc_bf16, tmp
     assert out[False][0] == out[True][0]
     for a, b in zip(out[False][1], out[True][1]):
         assert a.shape == b.shape and a.shape[0] > 0 and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", [False, True])
+def test_device_int16_conversion_equals_reference_rule(voc_bf16, norm):
+    """dtts_wav_to_int16 == utils/audio.py:11-16 per utterance over its own valid samples (wav / max|wav| if norm;
+    * 32767 in fp32; truncating astype(int16)), bit for bit; samples past an utterance's end are 0"""
+    from dict_tts_amd import infer
+    hop = voc_bf16.hop
+    rng = np.random.default_rng(5)
+    lens = np.array([7, 3, 0, 5], np.int32)
+    wav = rng.uniform(-1, 1, (4, 7 * hop)).astype(np.float32)
+    wav[0, :6] = [0.0, 0.5, -0.5, 0.99997, -1.0, 1.0]
+    wav[1] *= 0.01                                        # quiet utterance: norm matters
+    wav[1, 3 * hop:] = 0.9                                # beyond its end: must not enter its max
+    got = voc_bf16.to_int16(T(wav).cuda(), T(lens).cuda(), norm=norm).cpu().numpy()
+    assert got.dtype == np.int16 and got.shape == wav.shape
+    for b in range(4):
+        n = int(lens[b]) * hop
+        if n:
+            assert np.array_equal(got[b, :n], infer.wav_to_int16(wav[b, :n], norm)), b
+        assert not got[b, n:].any()
+    if not norm:
+        assert got[0, :6].tolist() == [0, 16383, -16383, 32766, -32767, 32767]

@@ -59,3 +59,26 @@ def test_int16_scaling_matches_reference_rule():
     x = np.array([0.0, 0.5, -0.5, 0.99997, -1.0], np.float32)
     assert infer.wav_to_int16(x).tolist() == [0, 16383, -16383, 32766, -32767]
     assert infer.wav_to_int16(x, norm=True).tolist() == [0, 16383, -16383, 32766, -32767]
+
+
+def test_pron_error_rate_counterpart(tmp_path):
+    """dict_tts_amd.per: gold syllables from the label csv's ph column, predicted syllables from meta.csv's
+    pinyin_tokens pairs, PER = WER(pred as truth, gold) * 100 (scripts/get_pron_error.py:9-18,31-47)"""
+    from dict_tts_amd import per
+    label = tmp_path / "label.csv"
+    label.write_text(",item_name,spk,txt,ph,wav_fn,others\n"
+                     "0,1,SPK1,卡尔普.,<BOS> k a3 | er3 | p u3 <EOS>,a.wav,{}\n"
+                     "1,2,SPK1,别再.,<BOS> b ie2 # z ai4 <EOS>,b.wav,{}\n", encoding="utf-8")
+    meta = tmp_path / "meta.csv"
+    meta.write_text(",item_name,text,pinyin_tokens,wav_fn_pred,wav_fn_gt\n"
+                    "0,1,卡尔普。,k a3 <UNK> er3 p u4,x,y\n"       # '<UNK> ' is dropped first, then tokens pair up by position
+                    "1,2,别再。,b ie2 z ai4,x,y\n", encoding="utf-8")
+    gold, n = per.gold_from_label_csv(str(label))
+    assert gold == ["ka3 er3 pu3", "bie2 zai4"] and n == 5
+    pred = per.pred_from_meta_csv(str(meta))
+    assert pred == ["ka3 er3p", "bie2 zai4"]                         # pairs are positional, as in the reference
+    assert per.edit_distance("a b c".split(), "a x c d".split()) == 2
+    assert per.wer(["a b c", "d"], ["a b c", "e"]) == 0.25
+    rate, _ = per.pron_error_rate(str(meta), str(label))
+    # pred as truth: "ka3 er3p" vs gold "ka3 er3 pu3" -> 1 substitution + 1 insertion over 4 predicted words
+    assert abs(rate - 100.0 * 2 / 4) < 1e-9
