@@ -29,7 +29,7 @@ PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARC
 DUR_BIAS = 3.09                        # exp(softplus(3.09)) - 1 ~= 22 frames per word
 
 
-def cpu_baseline(torch, np, synth, n_utt=6, max_seconds=40.0):
+def cpu_baseline(torch, np, synth, n_utt=20, max_seconds=25.0):
     """the CPU oracle (our restatement of the reference, oracle/*.py) timed on the host cores: reference-faithful
     protocol, B=1 per utterance, model forward + one spec2wav per utterance (tasks/tts/dict_tts.py:179-255)"""
     from oracle import dict_tts_ref as ref
@@ -311,15 +311,17 @@ def main():
         samples = value * voc.hop
         achieved = FLOP_PER_FRAME_VOCODER * frames_rank / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes of the same kernel family: PMC counters cannot be read from inside the process, so the committed
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE result of this command (profiles/r01_c_pmc_traffic.json, corrected
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE result of this command (profiles/r*_pmc_traffic.json, corrected
         # as MI355X_MICROARCH.md prescribes) is scaled by this run's frame count; null if the file is absent
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-        if args.precision == "bf16" and os.path.exists(tp):
+        import glob
+        tps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # the newest round's measurement
+        tp = tps[-1] if tps else ""
+        if args.precision == "bf16" and tp:
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_mel_frame"] * (frames_rank / max(args.steps, 1)) / max(conv_launches / max(args.steps, 1), 1)
-            traffic_src = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch, avg)"
+            traffic_src = f"profiles/{os.path.basename(tp)} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch, avg)"
         out = {
             "metric": "mel-frames/sec, end-to-end text->mel->wav (audio-samples/sec = 256x; RTF reported alongside)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
