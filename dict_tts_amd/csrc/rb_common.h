@@ -51,43 +51,56 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
 // One group of 4 k-steps of the contraction (see rb_contract).  CINIT: the very first MFMA of every accumulator tile
 // takes its C operand from cinit[n] (the bias pattern of this lane's 16 channel slots, identical for every row tile), so
 // the accumulators need no initialisation pass at all.
-template <int MT, int NT, int NKG, int PITCH, bool CINIT>
-__device__ __forceinline__ void rb_group(f32x16 (&acc)[MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[2][MT],
+// MH > 1: the wave owns MH * MT row tiles, processed as MH passes of MT tiles per weight fragment (pass h covers rows
+// h * MT * 32 ...): a weight fragment is fetched once per step and used for MH * MT MFMAs, while only 2 * MT activation
+// fragments are live at a time.
+template <int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1>
+__device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[2][MT],
                                          const char* act, const uint4* wpf, int xb, int dilP, int g) {
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
     constexpr int KGS = (NKG / 2) * 64;               // uint4 elements between consecutive steps (= NCT * 64, NCT = NKG / 2)
+    constexpr int HSTRIDE = MT * 32 * PITCH;          // LDS bytes between two passes
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
-        {   // activation fragments of step u+1
-            int off;
-            if constexpr (NKG >= 4) {
-                const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
-                off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
-            } else {
-                const int un = u + 1;                        // step within the group of TU taps
-                off = xb + (un / NKG) * dilP + (un % NKG) * 32;
+        for (int h = 0; h < MH; ++h) {
+            if (h == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
             }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                if constexpr (CINIT) {
-                    if (u == 0) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
-                                                                            cinit[n], 0, 0, 0);
-                        continue;
-                    }
+            {   // activation fragments of the next (step, pass)
+                int off;
+                if (h + 1 < MH) {
+                    // same step, next pass
+                    if constexpr (NKG >= 4) off = xb + ((g * 4 + u) % NKG) * 32 + (h + 1) * HSTRIDE;
+                    else off = xb + (u / NKG) * dilP + (u % NKG) * 32 + (h + 1) * HSTRIDE;
+                } else if constexpr (NKG >= 4) {
+                    const int kgn = (g * 4 + u + 1);            // k-group index within the tap (may be NKG: next tap)
+                    off = (u == 3 && g == GPT - 1) ? xb + dilP : xb + (kgn % NKG) * 32;
+                } else {
+                    const int un = u + 1;                        // step within the group of TU taps
+                    off = xb + (un / NKG) * dilP + (un % NKG) * 32;
                 }
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[u & 1][m],
-                                                                    acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[(u * MH + h + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
             }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (CINIT) {
+                        if (u == 0) {
+                            acc[h * MT + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                *(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[(u * MH + h) & 1][m], cinit[n], 0, 0, 0);
+                            continue;
+                        }
+                    }
+                    acc[h * MT + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        *(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[(u * MH + h) & 1][m], acc[h * MT + m][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -96,12 +109,13 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MT][NT], const f32x16 (&c
 // ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
 // activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
 // of guard rows, so the prefetches past the last step need no clamping.  CINIT: acc = cinit + W * act (acc not read).
-template <int MT, int NT, int NKG, int PITCH, bool CINIT = false>
-__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
+template <int MT, int NT, int NKG, int PITCH, bool CINIT = false, int MH = 1>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
                                             int S, int dilP, int kg_stride_unused, const f32x16 (*cinit)[NT] = nullptr) {
     constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
     constexpr int KGS = (NKG / 2) * 64;
+    static_assert(MH == 1 || (MH & 1) == 0, "the activation double buffer alternates per pass: MH must be 1 or even");
     uint4 xa[2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
@@ -111,7 +125,7 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)
     int s0 = 0;
     if constexpr (CINIT) {
         if (S > 0) {
-            rb_group<MT, NT, NKG, PITCH, true>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
+            rb_group<MT, NT, NKG, PITCH, true, MH>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
             s0 = 4;
             wpf += 4 * KGS;
             if constexpr (NKG >= 4) {
@@ -124,14 +138,14 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)
             }
         } else {   // ablation path (no contraction): acc = cinit
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MH * MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = (*cinit)[n];
         }
     }
     for (; s0 < S; s0 += 4) {
         const f32x16(&dummy)[NT] = *(const f32x16(*)[NT])acc[0];
-        rb_group<MT, NT, NKG, PITCH, false>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
+        rb_group<MT, NT, NKG, PITCH, false, MH>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
         wpf += 4 * KGS;
         if constexpr (NKG >= 4) {
             if (++g == GPT) {

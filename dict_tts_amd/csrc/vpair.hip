@@ -17,10 +17,12 @@
 
 namespace dtts {
 
-template <int C>
-__global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
+// TT = 128: 3 workgroups per CU; TT = 256: every weight fragment feeds 8 MFMAs instead of 4 (half the weight stream
+// through the texture path, half the halo), 2 workgroups per CU when the LDS tile allows
+template <int C, int TT>
+__global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPairParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = 1, TT = 128;
+    constexpr int MT = 4, NT = 1, MH = TT / 128, MTT = MT * MH;
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == 4, "one co-tile per wave");
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     __syncthreads();
 
     // ---- c1: xt rows r = 0..127  <->  global t0 - h2 + r ; reads staged rows r + tap * d
-    f32x16 acc[MT][NT];
+    f32x16 acc[MTT][NT];
     f32x16 cinit[NT];   // bias pattern of this lane's 16 channel slots: the C operand of every tile's first MFMA
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -84,12 +86,12 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b2 + wc * 32 + 8 * q + 4 * (lane >> 5));
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
-    rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
+    rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
     __syncthreads();   // every wave is done reading the x tile
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
 #pragma unroll
-    for (int m = 0; m < ((p.dbg & 8) ? 0 : MT); ++m) {
+    for (int m = 0; m < ((p.dbg & 8) ? 0 : MTT); ++m) {
         const int r = m * 32 + (lane & 31);
         const int t = t0 - h2 + r;
         const bool inb = t >= 0 && t < len;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) cinit[0][4 * q + e] = bb[q][e];
-    rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
+    rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
     if (p.dbg & 2) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
     };
     fetch(0, xin[0], sold[0]);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MTT; ++m) {
         if (m) __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[m][0][4 * q + e];
             *(f32x4*)(smem + (lane & 31) * EP + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
         }
-        if (m + 1 < MT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
+        if (m + 1 < MTT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -169,19 +171,19 @@ __global__ __launch_bounds__(256, 3) void vpair_kernel(const VPairParams p) {
 
 bool vpair_supported(int C, int K, int dil) { return C == 128 && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5; }
 
-hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
-    if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
+template <int TT>
+static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr int CC = 128, PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
-    const int TTe = 128 - 2 * h2;
-    // staged rows + one spare tap for the activation prefetch; the xt phase needs 128 + (K-1) + 1 rows, the epilogue 32 fp32 rows
-    size_t rows = (size_t)128 + 2 * h1 + p.dil + 1 + 8;   // + 8: the staging loop rounds the row count up to its step
-    if (rows < (size_t)128 + p.K + 1) rows = 128 + p.K + 1;
+    const int TTe = TT - 2 * h2;
+    // staged rows + one spare tap for the activation prefetch; the xt phase needs TT + (K-1) + 1 rows, the epilogue 32 fp32 rows
+    size_t rows = (size_t)TT + 2 * h1 + p.dil + 1 + 8;   // + 8: the staging loop rounds the row count up to its step
+    if (rows < (size_t)TT + p.K + 1) rows = TT + p.K + 1;
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
     if (const char* e = getenv("DTTS_VPAIR_LDS")) lds = std::max<size_t>(lds, (size_t)atoi(e) * 1024);  // occupancy experiment
-    auto kern = vpair_kernel<CC>;
+    auto kern = vpair_kernel<CC, TT>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -191,6 +193,15 @@ hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
     dim3 grid((p.T + TTe - 1) / TTe, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
+}
+
+hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
+    if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
+    static const int tt = getenv("DTTS_VPAIR_TT") ? atoi(getenv("DTTS_VPAIR_TT")) : 0;   // tuning switch: 128 / 256 / 0 = auto
+    // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
+    const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + p.dil + 1 + 8;
+    const bool big = tt == 256 || (tt == 0 && rows256 * (128 * 2 + 16) * 2 <= 160 * 1024);
+    return big ? vpair_launch_tt<256>(p, stream) : vpair_launch_tt<128>(p, stream);
 }
 
 } // namespace dtts
