@@ -175,222 +175,395 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
 // ---------------------------------------------------------------------------------------------------------
 // S2PA dictionary attention: one block per word, gloss rows streamed once with 16 B/lane loads.
 constexpr int S2PA_LMAX = 1024, S2PA_DMAX4 = 3;  // D <= 768 (3 float4 per lane), L_k <= 1024
-// S2PA_NW waves per word, each keeping S2PA_RU gloss rows (3 x 16 B per lane each) in flight
-template <int S2PA_NW, int S2PA_RU>
-__global__ __launch_bounds__(S2PA_NW * 64) void s2pa_kernel(const S2paArgs a) {
-    __shared__ float lg[S2PA_LMAX];
-    __shared__ float km[S2PA_LMAX];
-    __shared__ __attribute__((aligned(16))) float part[S2PA_NW][768];
-    __shared__ float red[2 * S2PA_NW];
-    __shared__ float sense[16];
-    __shared__ float pw[64];
-    __shared__ int pid[64 + 4];
-    constexpr int NTHR = S2PA_NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x;  // b * T_w + t
-    const int b = row / a.T_w, t = row % a.T_w;
-    const int L = a.L_k, D4 = a.D / 4;
-    // row sources: the collated tensors, or the resident table
+constexpr int S2PA_NW = 4, S2PA_RU = 4;           // waves per workgroup; gloss rows a wave keeps in flight (3 x 16 B per lane each)
+constexpr int S2PA_NTHR = S2PA_NW * 64;
+
+struct S2paShared {
+    float lg[S2PA_LMAX];
+    float km[S2PA_LMAX];
+    unsigned short idx[S2PA_LMAX];
+    __attribute__((aligned(16))) float part[S2PA_NW][768];
+    float red[2 * S2PA_NW];
+    float sense[16];
+    float pw[64];
+    int pid[64 + 4];
+    float sc[S2PA_MAXCH];
+    int n_live;
+};
+// where one word's rows come from: the collated tensors, or the resident table
+struct S2paRow {
     const float* kmr = nullptr;
     const f32x4* kb = nullptr;
     const f32x4* vb = nullptr;
     const int64_t* pin = nullptr;
     const int64_t* pmr = nullptr;
-    int Lrow = L, Prow = a.P;
-    int special = 0;  // -1 / -2 in table mode
+    int Lrow, Prow, special;  // special: -1 / -2 in table mode
+};
+__device__ __forceinline__ S2paRow s2pa_row(const S2paArgs& a, int row) {
+    S2paRow r;
+    r.Lrow = a.L_k;
+    r.Prow = a.P;
+    r.special = 0;
     if (a.entry) {
         const int e = a.entry[row];
         if (e >= 0) {
             const int o = a.t_off[e];
-            Lrow = min(a.t_off[e + 1] - o, L);
-            kmr = a.t_key_map + o;
-            kb = (const f32x4*)(a.t_keys + (long long)o * a.D);
-            vb = (const f32x4*)(a.t_values + (long long)o * a.D);
+            r.Lrow = min(a.t_off[e + 1] - o, a.L_k);
+            r.kmr = a.t_key_map + o;
+            r.kb = (const f32x4*)(a.t_keys + (long long)o * a.D);
+            r.vb = (const f32x4*)(a.t_values + (long long)o * a.D);
             const int po = a.t_poff[e];
-            Prow = min(a.t_poff[e + 1] - po, a.P);
-            pin = a.t_pinyin + po;
-            pmr = a.t_pinyin_map + po;
+            r.Prow = min(a.t_poff[e + 1] - po, a.P);
+            r.pin = a.t_pinyin + po;
+            r.pmr = a.t_pinyin_map + po;
         } else {
-            special = e;
-            Lrow = 0;
-            Prow = 0;
+            r.special = e;
+            r.Lrow = 0;
+            r.Prow = 0;
         }
     } else {
-        kmr = a.key_map + (long long)row * L;
-        kb = (const f32x4*)(a.keys + (long long)row * L * a.D);
-        vb = (const f32x4*)(a.values + (long long)row * L * a.D);
-        pin = a.pinyin + (long long)row * a.P;
-        pmr = a.pinyin_map + (long long)row * a.P;
+        r.kmr = a.key_map + (long long)row * a.L_k;
+        r.kb = (const f32x4*)(a.keys + (long long)row * a.L_k * a.D);
+        r.vb = (const f32x4*)(a.values + (long long)row * a.L_k * a.D);
+        r.pin = a.pinyin + (long long)row * a.P;
+        r.pmr = a.pinyin_map + (long long)row * a.P;
     }
-    // key_map row; every logit starts at its masked / zero-vector value, only rows that must be READ are listed
-    __shared__ unsigned short idx[S2PA_LMAX];
-    __shared__ int n_live;
-    for (int l = tid; l < L; l += NTHR) {
-        const float k = l < Lrow ? kmr[l] : (special == -1 ? 1.f : 0.f);
-        km[l] = k;
-        lg[l] = k == 0.f ? -1e9f : 0.f;   // key_map == 0: masked regardless of content; table-mode BOS / last row: zero gloss vector
+    return r;
+}
+// key_map row into LDS; every logit starts at its masked / zero-vector value; ordered list of the rows that must be
+// READ (ballot prefix by wave 0), so that the streaming loops run over dense work.  Returns the number of live rows;
+// when there is none (all logits -1e9: uniform softmax, every value row contributes) the list holds 0..Lrow-1.
+__device__ __forceinline__ int s2pa_list(S2paShared& sh, const S2paRow& r, int L, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int l = tid; l < L; l += S2PA_NTHR) {
+        const float k = l < r.Lrow ? r.kmr[l] : (r.special == -1 ? 1.f : 0.f);
+        sh.km[l] = k;
+        sh.lg[l] = k == 0.f ? -1e9f : 0.f;   // key_map == 0: masked regardless of content; table-mode BOS / last row: zero gloss vector
     }
-    // the query, 12 floats per lane
-    f32x4 q[S2PA_DMAX4];
-    const f32x4* qp = (const f32x4*)(a.qk + (long long)row * a.D);
-#pragma unroll
-    for (int c = 0; c < S2PA_DMAX4; ++c) q[c] = (lane + 64 * c < D4) ? qp[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    if (wave == 0) {   // ordered compaction of the unmasked rows (ballot prefix), so that the streaming loops below
-        int cnt = 0;   // run over dense work and can keep several rows in flight
-        for (int base = 0; base < Lrow; base += 64) {
+    if (wave == 0) {
+        int cnt = 0;
+        for (int base = 0; base < r.Lrow; base += 64) {
             const int l = base + lane;
-            const bool live = l < Lrow && km[l] != 0.f;
+            const bool live = l < r.Lrow && sh.km[l] != 0.f;
             const unsigned long long m = __ballot(live);
-            if (live) idx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)l;
+            if (live) sh.idx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)l;
             cnt += __popcll(m);
         }
-        if (cnt == 0)   // every row masked: all logits are -1e9, the softmax is uniform and every value row contributes
-            for (int l = lane; l < Lrow; l += 64) idx[l] = (unsigned short)l;
-        if (lane == 0) n_live = cnt;
+        if (cnt == 0)
+            for (int l = lane; l < r.Lrow; l += 64) sh.idx[l] = (unsigned short)l;
+        if (lane == 0) sh.n_live = cnt;
     }
     __syncthreads();
-    const int n = n_live;
-    // a word past the end of its utterance: its weights are still returned (dict_attn), its context is zeroed by the
-    // caller whatever the values are, so nothing is read for it
-    const bool dead = a.lens && t >= a.lens[b];
-    const int n_val = dead ? 0 : (n ? n : Lrow);
-    // logits: a wave takes 4 listed rows at a time - 12 independent 16-byte loads per lane before the first reduction
-    constexpr int RU = S2PA_RU;
-    for (int i = wave * RU; i < n; i += S2PA_NW * RU) {
-        f32x4 k[RU][S2PA_DMAX4];
-        int lr[RU];
-#pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            lr[j] = idx[min(i + j, n - 1)];
-            const f32x4* kr = kb + (long long)lr[j] * D4;
-#pragma unroll
-            for (int c = 0; c < S2PA_DMAX4; ++c)
-                k[j][c] = (lane + 64 * c < D4) ? kr[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < S2PA_DMAX4; ++c)
-                if (lane + 64 * c < D4) acc += k[j][c][0] * q[c][0] + k[j][c][1] * q[c][1] + k[j][c][2] * q[c][2] + k[j][c][3] * q[c][3];
-            acc = wave_sum(acc);
-            if (lane == 0 && i + j < n) lg[lr[j]] = acc;
-        }
-    }
+    return sh.n_live;
+}
+__device__ __forceinline__ float s2pa_block_max(S2paShared& sh, float v, int tid) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) sh.red[tid >> 6] = v;
     __syncthreads();
-    // softmax over l
-    float mx = -3.0e38f;
-    for (int l = tid; l < L; l += NTHR) mx = fmaxf(mx, lg[l]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
+    v = sh.red[0];
+#pragma unroll
+    for (int w = 1; w < S2PA_NW; ++w) v = fmaxf(v, sh.red[w]);
+    return v;
+}
+__device__ __forceinline__ float s2pa_block_sum(S2paShared& sh, float v, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sh.red[S2PA_NW + (tid >> 6)] = v;
     __syncthreads();
-    mx = red[0];
+    v = 0.f;
 #pragma unroll
-    for (int w = 1; w < S2PA_NW; ++w) mx = fmaxf(mx, red[w]);
-    float sm = 0.f;
-    for (int l = tid; l < L; l += NTHR) {
-        const float e = expf(lg[l] - mx);
-        lg[l] = e;
-        sm += e;
-    }
-    sm = wave_sum(sm);
-    if (lane == 0) red[S2PA_NW + wave] = sm;
-    __syncthreads();
-    sm = 0.f;
-#pragma unroll
-    for (int w = 0; w < S2PA_NW; ++w) sm += red[S2PA_NW + w];   // fixed order: reproducible
-    float* da = a.dict_attn + ((long long)b * L) * a.T_w + t;
-    for (int l = tid; l < L; l += NTHR) {
-        const float w = lg[l] / sm;
-        lg[l] = w;
-        da[(long long)l * a.T_w] = w;
-    }
-    __syncthreads();
-    // weighted sum of the value rows (rows with zero weight contribute exactly zero: skipped)
-    f32x4 acc[S2PA_DMAX4];
-#pragma unroll
-    for (int c = 0; c < S2PA_DMAX4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (masked rows have weight exactly 0 and rows >= Lrow are zero vectors: only the listed rows contribute)
-    for (int i = wave * RU; i < n_val; i += S2PA_NW * RU) {
-        f32x4 v[RU][S2PA_DMAX4];
-        float w[RU];
-#pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            const int l = idx[min(i + j, n_val - 1)];
-            w[j] = i + j < n_val ? lg[l] : 0.f;
-            const f32x4* vr = vb + (long long)l * D4;
-#pragma unroll
-            for (int c = 0; c < S2PA_DMAX4; ++c)
-                v[j][c] = (lane + 64 * c < D4) ? vr[lane + 64 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int j = 0; j < RU; ++j)
-#pragma unroll
-            for (int c = 0; c < S2PA_DMAX4; ++c) acc[c] += v[j][c] * w[j];
-    }
-#pragma unroll
-    for (int c = 0; c < S2PA_DMAX4; ++c)
-        if (lane + 64 * c < D4) *(f32x4*)&part[wave][(lane + 64 * c) * 4] = acc[c];
-    // sense weights s_i = sum_l w[l] [key_map == i], deterministic order
-    if (tid < 16) {
-        float s = 0.f;
-        if (tid >= 1)
-            for (int l = 0; l < L; ++l) s += (km[l] == (float)tid) ? lg[l] : 0.f;
-        sense[tid] = s;
-    }
-    __syncthreads();
-    for (int c = tid; c < a.D; c += NTHR) {
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < S2PA_NW; ++w) sum += part[w][c];
-        a.wv[(long long)row * a.D + c] = sum;
-    }
-    // pronunciation weights
+    for (int w = 0; w < S2PA_NW; ++w) v += sh.red[S2PA_NW + w];   // fixed order: reproducible
+    return v;
+}
+// the small per-word inputs of the tail, loaded at kernel start so that the tail has no dependent global loads
+struct S2paPre {
+    long long pm, id, mod;
+    int pm_max;
+};
+__device__ __forceinline__ S2paPre s2pa_prefetch(const S2paArgs& a, const S2paRow& r, int row, int tid) {
+    S2paPre p;
+    p.pm = 0;
+    p.id = 0;
     if (tid < a.P && tid < 64) {
-        const long long pm = tid < Prow ? pmr[tid] : (special == -1 ? 1 : 0);
-        float w = (pm >= 1 && pm < 16) ? sense[pm] : 0.f;
+        p.pm = tid < r.Prow ? r.pmr[tid] : (r.special == -1 ? 1 : 0);
+        p.id = tid < r.Prow ? r.pin[tid] : 0;
+    }
+    p.mod = a.pron_modified ? a.pron_modified[row] : 0;
+    p.pm_max = *a.pm_max;
+    return p;
+}
+// everything that needs only the normalised weights sh.lg[0..L) and sh.km: dict_attn (transposed, as the reference
+// returns it), the sense merge, the forced-pronunciation rule and the pinyin-embedding mix
+__device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, const S2paPre& pre, int row, int b, int t, int tid) {
+    const int L = a.L_k;
+    float* da = a.dict_attn + ((long long)b * L) * a.T_w + t;
+    for (int l = tid; l < L; l += S2PA_NTHR) da[(long long)l * a.T_w] = sh.lg[l];
+    // sense weights s_i = sum_l w[l] [key_map == i]: wave 0, lane = 16 j + i sums the rows l = j (mod 4) of sense i (4
+    // independent LDS streams instead of one 148-long dependent chain), partials merged in a fixed order
+    if (tid < 64) {
+        const int i = tid & 15, j = tid >> 4;
+        float s = 0.f;
+        if (i >= 1) {
+#pragma unroll 4
+            for (int l = j; l < L; l += 4) s += (sh.km[l] == (float)i) ? sh.lg[l] : 0.f;
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (tid < 16) sh.sense[tid] = s;
+    }
+    __syncthreads();
+    if (tid < a.P && tid < 64) {
+        const long long pm = pre.pm;
+        float w = (pm >= 1 && pm < 16) ? sh.sense[pm] : 0.f;
         if (a.language_zh && a.pron_modified) {
-            const long long mod = a.pron_modified[row];
-            if (mod >= 1 && mod <= (long long)(*a.pm_max)) {
+            const long long mod = pre.mod;
+            if (mod >= 1 && mod <= (long long)pre.pm_max) {
                 const float forced = (pm == mod) ? 1.f : 0.f;
                 w = (forced - w) + w;  // weights_ - weights.detach() + weights (layers/utils.py:114)
             }
         } else if (a.language_zh) {
             w = (w - w) + w;
         }
-        pw[tid] = w;
+        sh.pw[tid] = w;
         a.pron_attn[(long long)row * a.P + tid] = w;
-        long long id = tid < Prow ? pin[tid] : 0;
+        long long id = pre.id;
         if (id < 0 || id >= a.n_pinyin) id = 0;
-        pid[tid] = (int)id;
+        sh.pid[tid] = (int)id;
     }
     __syncthreads();
-    for (int c = tid; c < a.H; c += NTHR) {
+    for (int c = tid; c < a.H; c += S2PA_NTHR) {
         float s = 0.f;
         for (int p0 = 0; p0 < a.P; p0 += 4) {   // 4 embedding rows in flight, summed in p order
             float e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = p0 + j < a.P ? a.pinyin_emb[(long long)pid[p0 + j] * a.H + c] : 0.f;
+            for (int j = 0; j < 4; ++j) e[j] = p0 + j < a.P ? a.pinyin_emb[(long long)sh.pid[p0 + j] * a.H + c] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (p0 + j < a.P) s += pw[p0 + j] * e[j];
+                if (p0 + j < a.P) s += sh.pw[p0 + j] * e[j];
         }
         a.pron[(long long)row * a.H + c] = s;
     }
 }
-hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
-    if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
-    static const int cfg = getenv("DTTS_S2PA_CFG") ? atoi(getenv("DTTS_S2PA_CFG")) : 0;   // tuning switch
-    const dim3 grid(a.B * a.T_w);
-    switch (cfg) {
-    case 2: hipLaunchKernelGGL((s2pa_kernel<4, 8>), grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((s2pa_kernel<8, 4>), grid, dim3(512), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((s2pa_kernel<16, 2>), grid, dim3(1024), 0, s, a); break;
-    case 5: hipLaunchKernelGGL((s2pa_kernel<16, 4>), grid, dim3(1024), 0, s, a); break;
-    case 6: hipLaunchKernelGGL((s2pa_kernel<8, 8>), grid, dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL((s2pa_kernel<4, 4>), grid, dim3(256), 0, s, a); break;
+
+// Merge of a split word's per-chunk results: M = max m_c, S = sum s_c exp(m_c - M); weights and value sums are
+// rescaled by exp(m_c - M) / S; then the common tail.  sh.km / sh.idx (s2pa_list) must be in place.  Everything it
+// needs is requested up front (one load latency).
+__device__ __forceinline__ void s2pa_combine(S2paShared& sh, const S2paArgs& a, const S2paPre& pre, int row, int b, int t, int n, int nch,
+                                             int tid) {
+    const int L = a.L_k;
+    __shared__ float stat[2 * S2PA_MAXCH];
+    float st = 0.f;
+    if (tid < 2 * nch) st = a.part_stat[(long long)row * a.nch_max * 2 + tid];
+    float pv[3][4];   // up to 4 chunks (L_k <= 256) prefetched; more are read in the loop below
+    const int npre = min(nch, 4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            pv[j][c] = (c < npre && tid + j * S2PA_NTHR < a.D) ? a.part_v[((long long)row * a.nch_max + c) * a.D + tid + j * S2PA_NTHR] : 0.f;
+    if (tid < 2 * nch) stat[tid] = st;
+    __syncthreads();
+    if (tid == 0) {
+        if (n > 0) {
+            float M = -3.0e38f, S = 0.f;
+            for (int c = 0; c < nch; ++c) M = fmaxf(M, stat[2 * c]);
+            for (int c = 0; c < nch; ++c) {
+                const float f = expf(stat[2 * c] - M);
+                sh.sc[c] = f;
+                S += stat[2 * c + 1] * f;
+            }
+            for (int c = 0; c < nch; ++c) sh.sc[c] = sh.sc[c] / S;
+        } else {
+            for (int c = 0; c < nch; ++c) sh.sc[c] = 1.f / (float)L;   // all L logits equal: uniform softmax
+        }
     }
+    for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = n > 0 ? 0.f : 1.f / (float)L;   // masked rows: exp(-1e9 - M) == 0
+    __syncthreads();
+    if (n > 0)
+        for (int i = tid; i < n; i += S2PA_NTHR) {
+            const int l = sh.idx[i];
+            sh.lg[l] = a.part_e[(long long)row * L + l] * sh.sc[i / S2PA_CH];
+        }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int d = tid + j * S2PA_NTHR;
+        if (d < a.D) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < npre) sum += pv[j][c] * sh.sc[c];
+            for (int c = 4; c < nch; ++c) sum += a.part_v[((long long)row * a.nch_max + c) * a.D + d] * sh.sc[c];
+            a.wv[(long long)row * a.D + d] = sum;
+        }
+    }
+    __syncthreads();
+    s2pa_tail(sh, a, pre, row, b, t, tid);
+}
+
+// grid (words, chunks): workgroup (row, c) streams the live rows [c * S2PA_CH, (c + 1) * S2PA_CH) of word `row`.
+// A word with at most S2PA_CH live rows (almost all of them) is finished by its c = 0 workgroup; longer ones (the
+// BOS / last rows the collater pads with 148 all-ones key_map entries, the occasional long entry) leave per-chunk
+// partial results (local max, sum, unnormalised weights, weighted value sum) for s2pa_combine_kernel, so that no
+// workgroup streams more than S2PA_CH rows per pass and the launch has no long tail.
+__global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
+    __shared__ S2paShared sh;
+    constexpr int RU = S2PA_RU;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // row = b * T_w + t.  Workgroups are dispatched in blockIdx order: the high chunks go first (most of them belong to
+    // short words and exit at once), so that the chunks of a long word all start with the bulk instead of queueing behind it
+    const int row = blockIdx.x, c = gridDim.y - 1 - blockIdx.y;
+    const int b = row / a.T_w, t = row % a.T_w;
+    const int L = a.L_k, D4 = a.D / 4;
+    const S2paRow r = s2pa_row(a, row);
+    const S2paPre pre = s2pa_prefetch(a, r, row, tid);
+    // the query, 12 floats per lane
+    f32x4 q[S2PA_DMAX4];
+    const f32x4* qp = (const f32x4*)(a.qk + (long long)row * a.D);
+#pragma unroll
+    for (int cc = 0; cc < S2PA_DMAX4; ++cc) q[cc] = (lane + 64 * cc < D4) ? qp[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n = s2pa_list(sh, r, L, tid);
+    // a word past the end of its utterance: its weights are still returned (dict_attn), its context is zeroed by the
+    // caller whatever the values are, so nothing is read for it
+    const bool dead = a.lens && t >= a.lens[b];
+    const int n_val = dead ? 0 : (n ? n : r.Lrow);
+    const int nch = max(1, (max(n, n_val) + S2PA_CH - 1) / S2PA_CH);
+    if (c >= nch) return;
+    const bool multi = nch > 1;
+    if (c == 0 && tid == 0) a.nch[row] = nch;
+    const int lo = c * S2PA_CH;
+    const int hi = multi ? min(lo + S2PA_CH, n) : n;            // listed rows [lo, hi): keys
+    const int vhi = multi ? min(lo + S2PA_CH, n_val) : n_val;   // listed rows [lo, vhi): values
+    // logits: a wave takes RU listed rows at a time - 12 independent 16-byte loads per lane before the first reduction
+    for (int i = lo + wave * RU; i < hi; i += S2PA_NW * RU) {
+        f32x4 k[RU][S2PA_DMAX4];
+        int lr[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            lr[j] = sh.idx[min(i + j, hi - 1)];
+            const f32x4* kr = r.kb + (long long)lr[j] * D4;
+#pragma unroll
+            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                k[j][cc] = (lane + 64 * cc < D4) ? kr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                if (lane + 64 * cc < D4) acc += k[j][cc][0] * q[cc][0] + k[j][cc][1] * q[cc][1] + k[j][cc][2] * q[cc][2] + k[j][cc][3] * q[cc][3];
+            acc = wave_sum(acc);
+            if (lane == 0 && i + j < hi) sh.lg[lr[j]] = acc;
+        }
+    }
+    __syncthreads();
+    float cmx = 0.f, csm = 0.f;
+    if (!multi) {   // softmax over all l
+        float mx = -3.0e38f;
+        for (int l = tid; l < L; l += S2PA_NTHR) mx = fmaxf(mx, sh.lg[l]);
+        mx = s2pa_block_max(sh, mx, tid);
+        float sm = 0.f;
+        for (int l = tid; l < L; l += S2PA_NTHR) {
+            const float e = expf(sh.lg[l] - mx);
+            sh.lg[l] = e;
+            sm += e;
+        }
+        sm = s2pa_block_sum(sh, sm, tid);
+        for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = sh.lg[l] / sm;
+    } else if (n > 0) {   // chunk-local: max / exp / sum over this chunk's live rows only
+        float mx = -3.0e38f;
+        for (int i = lo + tid; i < hi; i += S2PA_NTHR) mx = fmaxf(mx, sh.lg[sh.idx[i]]);
+        cmx = s2pa_block_max(sh, mx, tid);
+        float sm = 0.f;
+        for (int i = lo + tid; i < hi; i += S2PA_NTHR) {
+            const float e = expf(sh.lg[sh.idx[i]] - cmx);
+            sh.lg[sh.idx[i]] = e;
+            sm += e;
+        }
+        csm = s2pa_block_sum(sh, sm, tid);
+    } else {   // no live row: every value row has the same weight (fixed up by the combine kernel)
+        for (int i = lo + tid; i < vhi; i += S2PA_NTHR) sh.lg[sh.idx[i]] = 1.f;
+    }
+    __syncthreads();
+    // weighted sum of the value rows (masked rows have weight exactly 0 and rows >= Lrow are zero vectors: only the
+    // listed rows contribute)
+    f32x4 acc[S2PA_DMAX4];
+#pragma unroll
+    for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = lo + wave * RU; i < vhi; i += S2PA_NW * RU) {
+        f32x4 v[RU][S2PA_DMAX4];
+        float w[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            const int l = sh.idx[min(i + j, vhi - 1)];
+            w[j] = i + j < vhi ? sh.lg[l] : 0.f;
+            const f32x4* vr = r.vb + (long long)l * D4;
+#pragma unroll
+            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                v[j][cc] = (lane + 64 * cc < D4) ? vr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j)
+#pragma unroll
+            for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] += v[j][cc] * w[j];
+    }
+#pragma unroll
+    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+        if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = acc[cc];
+    __syncthreads();
+    float* dst = multi ? a.part_v + ((long long)row * a.nch_max + c) * a.D : a.wv + (long long)row * a.D;
+    for (int d = tid; d < a.D; d += S2PA_NTHR) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d];
+        dst[d] = sum;
+    }
+    if (!multi) {
+        s2pa_tail(sh, a, pre, row, b, t, tid);
+        return;
+    }
+    if (n > 0)
+        for (int i = lo + tid; i < hi; i += S2PA_NTHR) a.part_e[(long long)row * L + sh.idx[i]] = sh.lg[sh.idx[i]];
+    if (tid == 0) {
+        a.part_stat[((long long)row * a.nch_max + c) * 2] = cmx;
+        a.part_stat[((long long)row * a.nch_max + c) * 2 + 1] = csm;
+    }
+}
+
+// the merge pass: one workgroup per word, words that were not split exit at once.  (Merging inside s2pa_kernel by the
+// chunk that arrives last needs device-scope release/acquire fences, which write back / invalidate a whole L2 on this
+// multi-XCD part: measured 235 us instead of 67 + 10.)
+__global__ __launch_bounds__(S2PA_NTHR) void s2pa_combine_kernel(const S2paArgs a) {
+    __shared__ S2paShared sh;
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const int nch = a.nch[row];
+    if (nch <= 1) return;
+    const S2paRow r = s2pa_row(a, row);
+    const S2paPre pre = s2pa_prefetch(a, r, row, tid);
+    const int n = s2pa_list(sh, r, a.L_k, tid);
+    s2pa_combine(sh, a, pre, row, row / a.T_w, row % a.T_w, n, nch, tid);
+}
+
+size_t s2pa_scratch_bytes(int rows, int L_k, int D) {
+    const size_t nch = (size_t)(L_k + S2PA_CH - 1) / S2PA_CH;
+    return (size_t)rows * (nch * D + L_k + nch * 2 + 1) * sizeof(float) + 1024;
+}
+hipError_t s2pa_launch(const S2paArgs& a0, void* scratch, hipStream_t s) {
+    if (a0.L_k > S2PA_LMAX || a0.D > 768 || (a0.D & 3) || a0.P > 64) return hipErrorInvalidValue;
+    S2paArgs a = a0;
+    const int rows = a.B * a.T_w;
+    a.nch_max = (a.L_k + S2PA_CH - 1) / S2PA_CH;
+    if (a.nch_max > S2PA_MAXCH) return hipErrorInvalidValue;
+    float* f = (float*)scratch;
+    a.part_v = f;
+    f += (size_t)rows * a.nch_max * a.D;
+    a.part_e = f;
+    f += (size_t)rows * a.L_k;
+    a.part_stat = f;
+    f += (size_t)rows * a.nch_max * 2;
+    a.nch = (int*)f;
+    hipLaunchKernelGGL(s2pa_kernel, dim3(rows, a.nch_max), dim3(S2PA_NTHR), 0, s, a);
+    if (a.nch_max > 1) hipLaunchKernelGGL(s2pa_combine_kernel, dim3(rows), dim3(S2PA_NTHR), 0, s, a);
     return hipGetLastError();
 }
 

@@ -374,3 +374,62 @@ def test_device_int16_conversion_equals_reference_rule(voc_bf16, norm):
         assert not got[b, n:].any()
     if not norm:
         assert got[0, :6].tolist() == [0, 16383, -16383, 32766, -32767, 32767]
+
+
+@pytest.mark.gpu
+def test_s2pa_split_words_vs_oracle_and_repeatable(acoustic, oracle_sd):
+    """words with more live gloss rows than one workgroup streams (S2PA_CH = 64) are split into chunks whose partial
+    softmax statistics are merged by a second pass: long NON-zero spans (so a stale or missing partial
+    would show), a long fully-masked word (uniform weights over all rows), a word past its utterance's end, chunk
+    boundaries at 64 / 65 / 128 / 129 live rows -- against the oracle, and bit-identical over repeated launches"""
+    from oracle import dict_tts_ref as ref
+    st = synth.biaobei_struct()
+    sents = [st["sentences"][i] for i in (2, 5, 9, 14)]
+    batch = synth.make_batch(sents, gc.SEED + 3, pron_every=2)
+    B, T_w, L0 = batch["key_map"].shape
+    L = 160                                               # widen the gloss axis (extra rows masked, as batch padding is)
+    for k in ("keys", "values", "key_map"):
+        pad = [(0, 0)] * batch[k].ndim
+        pad[2] = (0, L - L0)
+        batch[k] = np.ascontiguousarray(np.pad(batch[k], pad))
+    batch["key_map"][:, 0, :] = 1                         # the collater's BOS row: key_map all ones over the padded width
+    rng = np.random.default_rng(11)
+    D = batch["keys"].shape[-1]
+
+    def fill(b, t, n_live, senses=2):
+        km = np.zeros(L, np.float32)
+        km[1:1 + n_live] = rng.integers(1, senses + 1, n_live)
+        batch["key_map"][b, t] = km
+        batch["keys"][b, t] = rng.normal(0, 0.5, (L, D)).astype(np.float32)
+        batch["values"][b, t] = rng.normal(0, 0.5, (L, D)).astype(np.float32)
+
+    n_words = (batch["word_tokens"] > 0).sum(1)
+    assert n_words.min() >= 7
+    for b, (t, n_live) in enumerate([(1, 64), (2, 65), (3, 128), (4, 129)]):
+        fill(b, t, n_live)
+    fill(0, 5, L - 2, senses=3)
+    batch["key_map"][1, 5, :] = 0                        # long fully-masked word inside the utterance, non-zero values
+    batch["values"][1, 5] = rng.normal(0, 0.5, (L, D)).astype(np.float32)
+    short = int(np.argmin(n_words))
+    if n_words[short] < T_w:                              # a long live word past the end of a shorter utterance
+        fill(short, T_w - 1, 100)
+    b_t = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b_t["word_tokens"], (b_t["keys"], b_t["values"], b_t["key_map"], b_t["pinyin"], b_t["pinyin_map"]),
+                             b_t["pron_modified"], z_p=lambda B_, T4: T(synth.noise(9, B_, T4)))
+    T_mel = want["mel_out"].shape[1]
+    z = T(synth.noise(9, B, T_mel // 4))
+    first = None
+    for rep in range(12):
+        got = _run(acoustic, batch, z=z)
+        cur = {k: got[k].cpu() for k in ("dict_attn", "pron_attn", "word_encoder_out", "mel_out", "mel2word")}
+        if first is None:
+            first = cur
+            assert torch.equal(cur["mel2word"], want["mel2word"])
+            assert (cur["dict_attn"] - want["dict_attn"]).abs().max() <= 1e-5
+            assert (cur["pron_attn"] - want["pron_attn"]).abs().max() <= 1e-5
+            assert (cur["word_encoder_out"] - want["word_encoder_out"]).abs().max() <= 1e-4
+            assert (cur["mel_out"] - want["mel_out"]).abs().max() <= 1e-3
+            assert torch.allclose(cur["dict_attn"][1, 0, :, 5], torch.full((L,), 1.0 / L), atol=1e-6)
+        else:
+            for k in cur:
+                assert torch.equal(cur[k], first[k]), (rep, k)
