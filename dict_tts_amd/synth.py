@@ -130,6 +130,31 @@ def dict_tts_state_dict(seed=1234, n_phone=6, word_size=WORD_SIZE):
     return sd
 
 
+def fft_blocks_state_dict(seed=1234, hidden=HIDDEN, layers=4, kernel_size=9, use_pos_embed=True, use_last_norm=True):
+    """numpy state dict of the reference's ``FFTBlocks`` (modules/fastspeech/tts_modules.py:458-493): per layer
+    ``layers.i.op.{layer_norm1, self_attn.in_proj_weight, self_attn.out_proj, layer_norm2, ffn.ffn_1, ffn.ffn_2}``"""
+    sd = {}
+    for i in range(layers):
+        p = f"layers.{i}.op"
+        _ln(sd, seed, f"fft.{p}.layer_norm1", hidden, "weight", "bias")
+        sd[f"{p}.layer_norm1.weight"], sd[f"{p}.layer_norm1.bias"] = sd.pop(f"fft.{p}.layer_norm1.weight"), sd.pop(f"fft.{p}.layer_norm1.bias")
+        sd[f"{p}.self_attn.in_proj_weight"] = randn(seed, f"fft.{p}.in_proj", (3 * hidden, hidden), 1.0 / np.sqrt(hidden))
+        sd[f"{p}.self_attn.out_proj.weight"] = randn(seed, f"fft.{p}.out_proj", (hidden, hidden), 0.7 / np.sqrt(hidden))
+        _ln(sd, seed, f"fft.{p}.layer_norm2", hidden, "weight", "bias")
+        sd[f"{p}.layer_norm2.weight"], sd[f"{p}.layer_norm2.bias"] = sd.pop(f"fft.{p}.layer_norm2.weight"), sd.pop(f"fft.{p}.layer_norm2.bias")
+        sd[f"{p}.ffn.ffn_1.weight"] = randn(seed, f"fft.{p}.ffn_1.w", (4 * hidden, hidden, kernel_size), 1.6 / np.sqrt(hidden * kernel_size) * np.sqrt(kernel_size))
+        sd[f"{p}.ffn.ffn_1.bias"] = randn(seed, f"fft.{p}.ffn_1.b", (4 * hidden,), 0.05)
+        sd[f"{p}.ffn.ffn_2.weight"] = randn(seed, f"fft.{p}.ffn_2.w", (hidden, 4 * hidden), 0.7 / np.sqrt(4 * hidden))
+        sd[f"{p}.ffn.ffn_2.bias"] = randn(seed, f"fft.{p}.ffn_2.b", (hidden,), 0.05)
+    if use_last_norm:
+        _ln(sd, seed, "fft.layer_norm", hidden, "weight", "bias")
+        sd["layer_norm.weight"], sd["layer_norm.bias"] = sd.pop("fft.layer_norm.weight"), sd.pop("fft.layer_norm.bias")
+    if use_pos_embed:
+        sd["pos_embed_alpha"] = np.array([0.8], np.float32)
+        sd["embed_positions._float_tensor"] = np.zeros(1, np.float32)
+    return sd
+
+
 def hifigan_config():
     """egs/egs_bases/tts/vocoder/hifigan.yaml:3-10"""
     return {"resblock": "1", "upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4],

@@ -100,3 +100,25 @@ def g5_noise(B, T4, which):
 
 def g6_mel():
     return synth.random_mel(SEED, 32, "g6.mel")
+
+
+def g8_inputs(which):
+    """FFTBlocks cases.  'dec': hidden 192, 4 layers, k=9, positional embedding, last norm, three
+    utterances of 45 / 30 / 1 frames in a 45-frame batch, one VALID frame whose first channel is exactly 0 (the
+    reference's make_positions(x[..., 0]) treats it as padding: it gets no position and does not advance the count).
+    'enc': 2 layers, k=5, no positional embedding (how FastspeechEncoder runs the stack), lengths 20 / 13."""
+    from dict_tts_amd import synth
+    if which == "dec":
+        x = synth.randn(SEED, "g8.dec.x", (3, 45, 192), 1.0)
+        lens = np.array([45, 30, 1], np.int64)
+        x[0, 7, 0] = 0.0
+    else:
+        x = synth.randn(SEED, "g8.enc.x", (2, 20, 192), 1.0)
+        lens = np.array([20, 13], np.int64)
+    for b, n in enumerate(lens):
+        x[b, n:] = 0.0
+    return x, lens
+
+
+G8_CASES = {"dec": dict(layers=4, kernel_size=9, use_pos_embed=True, use_last_norm=True),
+            "enc": dict(layers=2, kernel_size=5, use_pos_embed=False, use_last_norm=True)}

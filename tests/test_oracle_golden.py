@@ -104,3 +104,22 @@ def test_g6_hifigan(golden_dir):
     _close(wav.view(-1), g["wav"], 2e-5)
     _close(href.spec2wav(hsd, synth.hifigan_config(), mel), g["wav"], 2e-5)
     assert wav.shape[-1] == 32 * 256
+
+
+@pytest.mark.parametrize("which", ["dec", "enc"])
+def test_g8_fft_blocks_oracle_vs_reference_golden(golden_dir, which):
+    """oracle/fft_blocks_ref.py vs the reference's FFTBlocks: positional embedding with the
+    first-channel-zero quirk, bias-free attention projections, k**-0.5 GELU FFN, LayerNorm bias leaking through the
+    SAME-padded conv at the sequence end, a 1-frame utterance"""
+    from oracle import fft_blocks_ref as fref
+    from dict_tts_amd import synth
+    g = np.load(os.path.join(golden_dir, "g8_fft_blocks.npz"))
+    cfg = gc.G8_CASES[which]
+    sd = {k: torch.from_numpy(v) for k, v in synth.fft_blocks_state_dict(gc.SEED, 192, **cfg).items()}
+    x, lens = gc.g8_inputs(which)
+    y = fref.fft_blocks(sd, torch.from_numpy(x), num_heads=2, kernel_size=cfg["kernel_size"],
+                        use_pos_embed=cfg["use_pos_embed"], use_last_norm=cfg["use_last_norm"])
+    assert y.shape == g[which + ".out"].shape
+    assert np.abs(y.numpy() - g[which + ".out"]).max() <= 2e-5
+    for b, n in enumerate(lens):
+        assert not bool((y[b, n:] != 0).any())          # padded frames are exactly zero
