@@ -13,13 +13,14 @@ LIB_PATH = os.path.join(_HERE, "libdicttts_hip.so")
 
 DTTS_F32, DTTS_I64 = 0, 1
 VOC_BF16, VOC_BF16X3 = 0, 1
-PART_ACOUSTIC, PART_VOCODER = 1, 2
+PART_ACOUSTIC, PART_VOCODER, PART_FFT = 1, 2, 4
 OUT_PRON_ATTN, OUT_DUR, OUT_MEL2WORD, OUT_DICT_ATTN, OUT_WORD_ENCODER_OUT, OUT_X_MASK, OUT_CONTEXT, OUT_MEL_LENS = range(1, 9)
 TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
 EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
-           "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
+           "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
+           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
 
 
 class DttsConfig(C.Structure):
@@ -32,7 +33,8 @@ class DttsConfig(C.Structure):
         "frames_multiple", "language_zh", "upsample_initial_channel", "n_upsamples")] + [
         ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("n_resblock_kernels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
-        ("vocoder_precision", C.c_int32)]
+        ("vocoder_precision", C.c_int32), ("fft_layers", C.c_int32), ("fft_kernel_size", C.c_int32),
+        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32)]
 
 
 class DttsError(RuntimeError):
@@ -71,6 +73,7 @@ def load_library(path=None):
     lib.dtts_length_regulate.argtypes = [vp, vp, vp, i32, i32, vp, i32, C.POINTER(C.c_int32), vp]
     lib.dtts_hifigan_hop.argtypes = [vp]
     lib.dtts_wav_to_int16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.dtts_fft_blocks_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dtts_timer_enable.argtypes = [vp, i32]
     lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dtts_timer_reset.argtypes = [vp]
@@ -175,6 +178,10 @@ class Context:
 
     def wav_to_int16(self, wav, lens, B, T, norm, out, stream):
         self._chk(self.lib.dtts_wav_to_int16(self.h, wav, lens or None, B, T, int(bool(norm)), out, stream), "dtts_wav_to_int16")
+
+    def fft_blocks_forward(self, x, lens, pos_table, n_pos, B, T, y, stream):
+        self._chk(self.lib.dtts_fft_blocks_forward(self.h, x, lens or None, pos_table or None, int(n_pos), B, T, y, stream),
+                  "dtts_fft_blocks_forward")
 
     def timer_enable(self, which):
         self._chk(self.lib.dtts_timer_enable(self.h, which), "dtts_timer_enable")

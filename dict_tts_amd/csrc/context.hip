@@ -103,7 +103,15 @@ struct dtts_ctx {
     std::string err;
     std::map<std::string, HostTensor> w;
     std::vector<void*> allocs;
-    bool acoustic_ready = false, vocoder_ready = false;
+    bool acoustic_ready = false, vocoder_ready = false, fft_ready = false;
+    // ---- FFT block stack
+    struct FftLayer {
+        PackedConv qkv, o, ffn1, ffn2;
+        float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    };
+    std::vector<FftLayer> fft;
+    float *fft_g = nullptr, *fft_b = nullptr, *fft_alpha = nullptr;
+    Arena a_fft;
     // ---- acoustic model
     float *word_emb = nullptr, *pinyin_emb = nullptr;
     Encoder sem, lin;
@@ -916,6 +924,10 @@ void dtts_default_config(dtts_config* c) {
         c->resblock_dilation_sizes[i][2] = 5;
     }
     c->vocoder_precision = DTTS_VOC_BF16;
+    c->fft_layers = 4;
+    c->fft_kernel_size = 9;
+    c->fft_use_pos_embed = 1;
+    c->fft_use_last_norm = 1;
 }
 
 int dtts_create(const dtts_config* cfg, dtts_handle* out) {
@@ -938,6 +950,7 @@ void dtts_destroy(dtts_handle h) {
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->amax_bits) (void)hipFree(h->amax_bits);
+    h->a_fft.release();
     h->a_enc.release();
     h->a_dec.release();
     h->a_voc.release();
@@ -959,18 +972,136 @@ int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, cons
     return DTTS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// FFT block stack (FFTBlocks / EncSALayer): the same fp32-MFMA convolution, attention and LayerNorm
+// kernels as the S2PA encoders, with torch-LayerNorm eps, bias-free attention projections and the k**-0.5 GELU FFN
+namespace {
+int build_fft(dtts_ctx* h) {
+    Need need{h, ""};
+    const dtts_config& c = h->cfg;
+    const int C = c.hidden_size, K = c.fft_kernel_size;
+    if (c.fft_layers <= 0 || K <= 0 || !(K & 1) || C % c.num_heads || C / c.num_heads > 96)
+        return fail(h, DTTS_E_INVAL, "FFT blocks: unsupported configuration (layers=%d kernel=%d hidden=%d heads=%d)", c.fft_layers, K, C,
+                    c.num_heads);
+    h->fft.resize(c.fft_layers);
+    bool ok = true;
+    for (int i = 0; i < c.fft_layers && ok; ++i) {
+        dtts_ctx::FftLayer& l = h->fft[i];
+        const std::string p = "fft.layers." + std::to_string(i) + ".op.";
+        const HostTensor* win = need.get(p + "self_attn.in_proj_weight");   // [3C][C], no bias (EncSALayer: bias=False)
+        const HostTensor* wout = need.get(p + "self_attn.out_proj.weight");
+        if (!win || !wout) {
+            ok = false;
+            break;
+        }
+        if (win->numel() != (int64_t)3 * C * C || wout->numel() != (int64_t)C * C)
+            return fail(h, DTTS_E_INVAL, "%sself_attn: projection shapes do not match hidden_size %d", p.c_str(), C);
+        const float *pi = win->f.data(), *po = wout->f.data();
+        ok = ok && pack_conv(h, l.qkv, ENG_F32, 3 * C, C, 1, [=](int co, int ci, int) { return pi[(size_t)co * C + ci]; },
+                             std::vector<float>(), 1, 1, 0);
+        ok = ok && pack_conv(h, l.o, ENG_F32, C, C, 1, [=](int co, int ci, int) { return po[(size_t)co * C + ci]; },
+                             std::vector<float>(), 1, 1, 0);
+        ok = ok && pack_plain(h, need, l.ffn1, ENG_F32, p + "ffn.ffn_1", 1, 1, K / 2);
+        ok = ok && pack_plain(h, need, l.ffn2, ENG_F32, p + "ffn.ffn_2", 1, 1, 0);
+        if (ok && (l.ffn1.K != K || l.ffn1.C_out != 4 * C))
+            return fail(h, DTTS_E_INVAL, "%sffn.ffn_1: kernel %d / width %d differ from the configuration (%d / %d)", p.c_str(), l.ffn1.K,
+                        l.ffn1.C_out, K, 4 * C);
+        l.g1 = upload_named(h, need, p + "layer_norm1.weight");
+        l.b1 = upload_named(h, need, p + "layer_norm1.bias");
+        l.g2 = upload_named(h, need, p + "layer_norm2.weight");
+        l.b2 = upload_named(h, need, p + "layer_norm2.bias");
+        ok = ok && l.g1 && l.b1 && l.g2 && l.b2;
+    }
+    if (ok && c.fft_use_last_norm) {
+        h->fft_g = upload_named(h, need, "fft.layer_norm.weight");
+        h->fft_b = upload_named(h, need, "fft.layer_norm.bias");
+        ok = h->fft_g && h->fft_b;
+    }
+    if (ok && c.fft_use_pos_embed && h->w.count("fft.pos_embed_alpha"))   // absent with use_pos_embed_alpha=False: alpha = 1
+        ok = (h->fft_alpha = upload_named(h, need, "fft.pos_embed_alpha")) != nullptr;
+    if (!ok) {
+        if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
+        return h->err.empty() ? fail(h, DTTS_E_HIP, "FFT blocks: weight upload failed") : DTTS_E_HIP;
+    }
+    h->fft_ready = true;
+    return DTTS_OK;
+}
+} // namespace
+
+int dtts_fft_blocks_forward(dtts_handle h, const float* x_in, const int32_t* lens_in, const float* pos_table, int n_pos, int B, int T,
+                            float* y, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->fft_ready) return fail(h, DTTS_E_STATE, "FFT block weights not finalized");
+    const dtts_config& c = h->cfg;
+    if (!x_in || !y || B <= 0 || T <= 0) return fail(h, DTTS_E_INVAL, "dtts_fft_blocks_forward: bad argument");
+    if (c.fft_use_pos_embed && (!pos_table || n_pos <= T))
+        return fail(h, DTTS_E_INVAL, "dtts_fft_blocks_forward: the stack uses positional embeddings, pos_table needs > T = %d rows (got %d)", T,
+                    pos_table ? n_pos : 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = c.hidden_size, F = 4 * C;
+    const size_t rows = (size_t)B * T;
+    HIPCHK(h->a_fft.reserve(rows * (size_t)(C + C + 3 * C + C + F) * sizeof(float) + (size_t)B * sizeof(int) + (64 << 10)));
+    Arena& A = h->a_fft;
+    float* x = A.alloc<float>(rows * C);
+    float* hb = A.alloc<float>(rows * C);
+    float* qkv = A.alloc<float>(rows * 3 * C);
+    float* att = A.alloc<float>(rows * C);
+    float* ff = A.alloc<float>(rows * F);
+    int* lens = A.alloc<int>(B);
+    if (!x || !hb || !qkv || !att || !ff || !lens) return fail(h, DTTS_E_NOMEM, "FFT workspace");
+    // padding_mask = x.abs().sum(-1).eq(0) unless the caller has the lengths (tts_modules.py:501)
+    if (lens_in) HIPCHK(hipMemcpyAsync(lens, lens_in, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
+    else LAUNCH(rowcount_nonzero_launch(x_in, lens, B, T, C, s));
+    // x = (x + alpha * positions) * nonpadding (:503-509)
+    LAUNCH(fft_input_launch(x_in, c.fft_use_pos_embed ? pos_table : nullptr, n_pos, h->fft_alpha, lens, x, B, T, C, s));
+    const float kscale = (float)std::pow((double)c.fft_kernel_size, -0.5);
+    for (size_t i = 0; i < h->fft.size(); ++i) {   // EncSALayer.forward (common_layers.py:649-673)
+        const dtts_ctx::FftLayer& l = h->fft[i];
+        LAUNCH(layernorm_launch(x, hb, l.g1, l.b1, 1e-5f, lens, 0, 0, B, T, C, s));
+        ConvParams p = base_params(hb, C, B, T, T, qkv, 3 * C);
+        p.out_lens = lens;   // tiles wholly past the utterance's end are skipped (left unwritten: the attention kernel never reads them)
+        LAUNCH(conv1d_launch(l.qkv, p, s));
+        // keys past the utterance's end are masked (-1e4 fill: their softmax weight underflows to exactly 0, as with
+        // the reference's -inf); query rows past the end are zeroed by the residual epilogue below
+        LAUNCH(mha_launch(qkv, att, lens, B, T, C, c.num_heads, s));
+        p = base_params(att, C, B, T, T, x, C);
+        set_res(p, 0, x, C);
+        p.out_lens = lens;
+        p.zero_masked = 1;
+        LAUNCH(conv1d_launch(l.o, p, s));
+        LAUNCH(layernorm_launch(x, hb, l.g2, l.b2, 1e-5f, lens, 0, 0, B, T, C, s));
+        // TransformerFFNLayer (:558-581): the conv reads the LayerNorm output of padded frames too (= its bias), as the
+        // reference's SAME-padded Conv1d does; (conv + bias) * k**-0.5 -> GELU
+        p = base_params(hb, C, B, T, T, ff, F);
+        p.out_lens = lens;   // dead tiles skipped: ffn_2 is 1x1 and its rows past the end are written as zeros whatever it reads
+        p.out_mul = kscale;
+        p.post_act = 3;
+        LAUNCH(conv1d_launch(l.ffn1, p, s));
+        p = base_params(ff, F, B, T, T, x, C);
+        set_res(p, 0, x, C);
+        p.out_lens = lens;
+        p.zero_masked = 1;
+        LAUNCH(conv1d_launch(l.ffn2, p, s));
+    }
+    if (c.fft_use_last_norm) LAUNCH(layernorm_launch(x, y, h->fft_g, h->fft_b, 1e-5f, lens, 0, 1, B, T, C, s));
+    else HIPCHK(hipMemcpyAsync(y, x, rows * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DTTS_OK;
+}
+
 int dtts_finalize_weights(dtts_handle h, int parts) {
     if (!h) return DTTS_E_INVAL;
     h->err.clear();
     int rc = DTTS_OK;
     if ((parts & DTTS_PART_ACOUSTIC) && !h->acoustic_ready) rc = build_acoustic(h);
     if (rc == DTTS_OK && (parts & DTTS_PART_VOCODER) && !h->vocoder_ready) rc = build_vocoder(h);
+    if (rc == DTTS_OK && (parts & DTTS_PART_FFT) && !h->fft_ready) rc = build_fft(h);
     if (rc == DTTS_OK) {
         // host copies are no longer needed for finished parts
         for (auto it = h->w.begin(); it != h->w.end();) {
             const bool a = it->first.rfind("model.", 0) == 0 && h->acoustic_ready;
             const bool v = it->first.rfind("vocoder.", 0) == 0 && h->vocoder_ready;
-            it = (a || v) ? h->w.erase(it) : std::next(it);
+            const bool f = it->first.rfind("fft.", 0) == 0 && h->fft_ready;
+            it = (a || v || f) ? h->w.erase(it) : std::next(it);
         }
     }
     return rc;

@@ -38,7 +38,7 @@ struct ConvParams {
     int K, dil, stride, pad;
     int pre_act;         // 0 none; 1 = leaky-relu with pre_slope applied to the input while staging (slope 0 = relu)
     float pre_slope;
-    int post_act;        // 0 none, 1 relu, 2 tanh
+    int post_act;        // 0 none, 1 relu, 2 tanh, 3 gelu (erf form)
     int zero_masked;     // write zeros to rows >= out_len (else: leave untouched)
     float out_div;       // 1.0 or e.g. 3.0 (true division, as the reference's xs / num_kernels)
     float out_mul;       // 1.0 or a scale applied after bias (S2PA's q * key_size**-0.5)

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                     if (p.out_mul != 1.f) v = v * p.out_mul;
                     if (p.post_act == 1) v = fmaxf(v, 0.f);
                     else if (p.post_act == 2) v = tanhf(v);
+                    else if (p.post_act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // F.gelu (erf form)
                 }
                 sg.y[row * sg.ld + sg.coff + cs] = v;
             }

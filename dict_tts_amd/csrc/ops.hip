@@ -97,21 +97,32 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* qkv, float* out, 
     __shared__ float ps[MHA_QT][MHA_KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * MHA_QT;
-    const int len = lens ? lens[b] : T;
+    const int len = lens ? min(max(lens[b], 0), T) : T;
     const float* base = qkv + (long long)b * T * 3 * C;
     const float inv_sqrt = 1.0f / sqrtf((float)dk);
+    if (q0 >= len) {   // a tile of padded queries: every caller masks these rows; zeros instead of attention over nothing
+        for (int idx = tid; idx < MHA_QT * dk; idx += 256) {
+            const int i = idx / dk, d = idx % dk;
+            if (q0 + i < T) out[((long long)b * T + q0 + i) * C + h * dk + d] = 0.f;
+        }
+        return;
+    }
+    // keys past the utterance's end carry the -1e4 fill: their softmax weight exp(-1e4 - max) is exactly 0 in fp32 for
+    // every valid query, so whole key tiles beyond `len` are skipped and the rows beyond it inside the last tile are
+    // loaded as zeros (they may be uninitialised: their producers skip dead tiles too).  Bit-identical for valid rows.
+    const int kend = len;
     for (int idx = tid; idx < MHA_QT * dk; idx += 256) {
         const int i = idx / dk, d = idx % dk;
-        qs[i][d] = (q0 + i < T) ? base[(long long)(q0 + i) * 3 * C + h * dk + d] : 0.f;
+        qs[i][d] = (q0 + i < len) ? base[(long long)(q0 + i) * 3 * C + h * dk + d] : 0.f;
     }
     float m[4], l[4], o0[4], o1[4];
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) { m[qi] = -1e30f; l[qi] = 0.f; o0[qi] = 0.f; o1[qi] = 0.f; }
-    for (int j0 = 0; j0 < T; j0 += MHA_KT) {
+    for (int j0 = 0; j0 < kend; j0 += MHA_KT) {
         __syncthreads();
         for (int idx = tid; idx < MHA_KT * dk; idx += 256) {
             const int j = idx / dk, d = idx % dk;
-            const bool ok = j0 + j < T;
+            const bool ok = j0 + j < kend;
             const float* r = base + (long long)(j0 + j) * 3 * C + h * dk + d;
             ks[j][d] = ok ? r[C] : 0.f;
             vs[j][d] = ok ? r[2 * C] : 0.f;
@@ -564,6 +575,55 @@ hipError_t s2pa_launch(const S2paArgs& a0, void* scratch, hipStream_t s) {
     a.nch = (int*)f;
     hipLaunchKernelGGL(s2pa_kernel, dim3(rows, a.nch_max), dim3(S2PA_NTHR), 0, s, a);
     if (a.nch_max > 1) hipLaunchKernelGGL(s2pa_combine_kernel, dim3(rows), dim3(S2PA_NTHR), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- FFTBlocks input stage: positions by a block scan over one utterance, then the embedding add and the mask
+__global__ __launch_bounds__(256) void fft_input_kernel(const float* x, const float* table, int n_pos, const float* alpha,
+                                                        const int* lens, float* y, int T, int C) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = lens ? lens[b] : T;
+    const float al = alpha ? *alpha : 1.f;
+    const float* xb = x + (long long)b * T * C;
+    float* yb = y + (long long)b * T * C;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + tid;
+        const bool nz = table && t < T && xb[(long long)t * C] != 0.f;
+        const unsigned long long m = __ballot(nz);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int pos = nz ? base + before + 1 : 0;
+        if (pos >= n_pos) pos = 0;   // cannot happen when n_pos > T; keeps the gather in range
+        __syncthreads();
+        if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        // the 256 frames of this pass, channel-parallel: every wave takes frames, lanes take channels
+        __shared__ int pbuf[256];
+        pbuf[tid] = pos;
+        __syncthreads();
+        const int nt = min(256, T - t0);
+        for (int i = wave; i < nt; i += 4) {
+            const int tt = t0 + i;
+            const bool keep = tt < len;
+            const float* tr = table ? table + (long long)pbuf[i] * C : nullptr;
+            for (int c = lane; c < C; c += 64) {
+                float v = xb[(long long)tt * C + c];
+                if (tr) v = __fadd_rn(v, __fmul_rn(al, tr[c]));   // two roundings, as x + alpha * positions
+                yb[(long long)tt * C + c] = keep ? v : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const float* alpha, const int* lens, float* y, int B,
+                            int T, int C, hipStream_t s) {
+    hipLaunchKernelGGL(fft_input_kernel, dim3(B), dim3(256), 0, s, x, table, n_pos, alpha, lens, y, T, C);
     return hipGetLastError();
 }
 

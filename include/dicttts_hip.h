@@ -75,6 +75,11 @@ typedef struct dtts_config {
     int32_t resblock_kernel_sizes[4]; /* 3,7,11 */
     int32_t resblock_dilation_sizes[4][3]; /* (1,3,5) x3 */
     int32_t vocoder_precision;        /* DTTS_VOC_BF16 | DTTS_VOC_BF16X3 */
+    /* FFT block stack (FFTBlocks, modules/fastspeech/tts_modules.py:458-493); width = hidden_size, heads = num_heads */
+    int32_t fft_layers;               /* dec_layers 4                          egs/egs_bases/tts/base.yaml:68 */
+    int32_t fft_kernel_size;          /* dec_ffn_kernel_size 9                 base.yaml:72                   */
+    int32_t fft_use_pos_embed;        /* FFTBlocks(use_pos_embed=True)                                        */
+    int32_t fft_use_last_norm;        /* FFTBlocks(use_last_norm=True)                                        */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
@@ -98,6 +103,7 @@ int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, cons
 
 #define DTTS_PART_ACOUSTIC 1
 #define DTTS_PART_VOCODER 2
+#define DTTS_PART_FFT 4 /* an FFTBlocks state dict loaded under "fft.<key>"  */
 /* Fold, repack into MFMA fragment order and upload.  Fails with DTTS_E_NOENT naming the first missing tensor. */
 int dtts_finalize_weights(dtts_handle h, int parts);
 
@@ -173,6 +179,18 @@ int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ile
 int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* lens_dev, int B, int T, float* wav_dev,
                          dtts_stream stream);
 int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
+
+/*
+ * FastSpeech FFT block stack — replaces FFTBlocks.forward (modules/fastspeech/tts_modules.py:495-523) at inference:
+ * x [B,T,hidden] f32 -> y [B,T,hidden] f32.  lens [B] i32 = valid frames per utterance, or NULL: derived from the
+ * values as the reference does (frames whose |x| sums to zero are padding; padding must be a suffix).
+ * pos_table [n_pos][hidden] f32 = SinusoidalPositionalEmbedding.weights (modules/commons/common_layers.py:110-127,
+ * row 0 = padding) when the stack was built with use_pos_embed, n_pos > T; otherwise NULL.  Positions follow
+ * make_positions(x[...,0]) (utils/tts_utils.py:6-18): a frame whose first channel is exactly 0 gets row 0.
+ * Weights: dtts_load_weight("fft.<key of FFTBlocks.state_dict()>"), dtts_finalize_weights(h, DTTS_PART_FFT).
+ */
+int dtts_fft_blocks_forward(dtts_handle h, const float* x_dev, const int32_t* lens_dev, const float* pos_table_dev, int n_pos,
+                            int B, int T, float* y_dev, dtts_stream stream);
 
 /*
  * Output side — replaces the sample conversion of save_wav (utils/audio.py:11-16; called from after_infer,

@@ -433,3 +433,51 @@ def test_s2pa_split_words_vs_oracle_and_repeatable(acoustic, oracle_sd):
         else:
             for k in cur:
                 assert torch.equal(cur[k], first[k]), (rep, k)
+
+
+# ------------------------------------------------------------------------------------------------ FFT blocks
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["dec", "enc"])
+def test_g8_fft_blocks_vs_reference_golden(golden_dir, which):
+    """dict_tts_amd.fft.FFTBlocks (dtts_fft_blocks_forward) vs the reference's FFTBlocks outputs: value-derived padding,
+    positional embedding incl. the first-channel-zero quirk, bias-free attention, k**-0.5 GELU FFN with the LayerNorm
+    bias of padded frames leaking through the SAME-padded conv, a 1-frame utterance; and with explicit padding_mask"""
+    from dict_tts_amd import fft
+    g = np.load(os.path.join(golden_dir, "g8_fft_blocks.npz"))
+    cfg = gc.G8_CASES[which]
+    m = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=cfg["kernel_size"], num_heads=2, use_pos_embed=cfg["use_pos_embed"],
+                      use_last_norm=cfg["use_last_norm"], hparams={})
+    m.load_state_dict({k: T(v) for k, v in synth.fft_blocks_state_dict(gc.SEED, 192, **cfg).items()})
+    x, lens = gc.g8_inputs(which)
+    y = m(T(x)).cpu().numpy()
+    want = g[which + ".out"]
+    assert y.shape == want.shape
+    assert np.abs(y - want).max() <= 1e-4, np.abs(y - want).max()
+    for b, n in enumerate(lens):
+        assert not (y[b, n:] != 0).any()
+    pm = T(np.arange(x.shape[1])[None, :] >= lens[:, None])
+    y2 = m(T(x), padding_mask=pm).cpu().numpy()
+    assert np.array_equal(y, y2)
+
+
+@pytest.mark.gpu
+def test_fft_blocks_long_batch_vs_oracle_and_missing_weight():
+    """decoder-sized problem (B=6, T=700 mel frames, ragged) against the oracle; a missing tensor is named"""
+    from oracle import fft_blocks_ref as fref
+    from dict_tts_amd import fft
+    cfg = gc.G8_CASES["dec"]
+    sd = synth.fft_blocks_state_dict(gc.SEED + 1, 192, **cfg)
+    m = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=9, num_heads=2, hparams={})
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    x = synth.randn(gc.SEED, "fft.long.x", (6, 700, 192), 1.0)
+    lens = [700, 512, 333, 64, 65, 7]
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    want = fref.fft_blocks({k: T(v) for k, v in sd.items()}, T(x), num_heads=2, kernel_size=9)
+    got = m(T(x)).cpu()
+    assert (got - want).abs().max() <= 2e-4, float((got - want).abs().max())
+    bad = dict(sd)
+    del bad["layers.2.op.ffn.ffn_2.bias"]
+    m2 = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=9, num_heads=2, hparams={})
+    with pytest.raises(RuntimeError, match="layers.2.op.ffn.ffn_2.bias"):
+        m2.load_state_dict({k: T(v) for k, v in bad.items()})
