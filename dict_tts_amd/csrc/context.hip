@@ -1040,7 +1040,7 @@ int dtts_fft_blocks_forward(dtts_handle h, const float* x_in, const int32_t* len
     hipStream_t s = (hipStream_t)stream;
     const int C = c.hidden_size, F = 4 * C;
     const size_t rows = (size_t)B * T;
-    HIPCHK(h->a_fft.reserve(rows * (size_t)(C + C + 3 * C + C + F) * sizeof(float) + (size_t)B * sizeof(int) + (64 << 10)));
+    HIPCHK(h->a_fft.reserve(rows * (size_t)(C + C + 3 * C + C + F + 1) * sizeof(float) + (size_t)B * sizeof(int) + (64 << 10)));
     Arena& A = h->a_fft;
     float* x = A.alloc<float>(rows * C);
     float* hb = A.alloc<float>(rows * C);
@@ -1048,12 +1048,13 @@ int dtts_fft_blocks_forward(dtts_handle h, const float* x_in, const int32_t* len
     float* att = A.alloc<float>(rows * C);
     float* ff = A.alloc<float>(rows * F);
     int* lens = A.alloc<int>(B);
-    if (!x || !hb || !qkv || !att || !ff || !lens) return fail(h, DTTS_E_NOMEM, "FFT workspace");
+    int* pos = A.alloc<int>(rows);
+    if (!x || !hb || !qkv || !att || !ff || !lens || !pos) return fail(h, DTTS_E_NOMEM, "FFT workspace");
     // padding_mask = x.abs().sum(-1).eq(0) unless the caller has the lengths (tts_modules.py:501)
     if (lens_in) HIPCHK(hipMemcpyAsync(lens, lens_in, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
     else LAUNCH(rowcount_nonzero_launch(x_in, lens, B, T, C, s));
     // x = (x + alpha * positions) * nonpadding (:503-509)
-    LAUNCH(fft_input_launch(x_in, c.fft_use_pos_embed ? pos_table : nullptr, n_pos, h->fft_alpha, lens, x, B, T, C, s));
+    LAUNCH(fft_input_launch(x_in, c.fft_use_pos_embed ? pos_table : nullptr, n_pos, h->fft_alpha, lens, pos, x, B, T, C, s));
     const float kscale = (float)std::pow((double)c.fft_kernel_size, -0.5);
     for (size_t i = 0; i < h->fft.size(); ++i) {   // EncSALayer.forward (common_layers.py:649-673)
         const dtts_ctx::FftLayer& l = h->fft[i];

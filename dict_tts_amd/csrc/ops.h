@@ -106,8 +106,9 @@ hipError_t wav_to_int16_launch(const float* wav, const int* lens, int hop, int B
 // FFTBlocks input stage (tts_modules.py:503-509): y[b,t,:] = (x[b,t,:] + alpha * table[pos[b,t]]) * (t < lens[b]) with
 // pos = make_positions(x[...,0], 0) = running count of frames whose first channel is non-zero (0 for the others);
 // table == null: y = x * (t < lens[b]).  alpha is a device scalar (pos_embed_alpha) or null = 1.
-hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const float* alpha, const int* lens, float* y, int B,
-                            int T, int C, hipStream_t s);
+// pos_scratch: [B][T] i32 (used when table != null).
+hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const float* alpha, const int* lens, int* pos_scratch,
+                            float* y, int B, int T, int C, hipStream_t s);
 
 // [B][C][T] -> [B][T][C] transpose (z_p arrives channels-first as the reference samples it)
 hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s);

@@ -578,52 +578,52 @@ hipError_t s2pa_launch(const S2paArgs& a0, void* scratch, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- FFTBlocks input stage: positions by a block scan over one utterance, then the embedding add and the mask
-__global__ __launch_bounds__(256) void fft_input_kernel(const float* x, const float* table, int n_pos, const float* alpha,
-                                                        const int* lens, float* y, int T, int C) {
+// ---- FFTBlocks input stage: positions by a block scan over one utterance's first channel, then a row-parallel
+// embedding add + mask
+__global__ __launch_bounds__(256) void fft_positions_kernel(const float* x, int* pos, int n_pos, int T, int C) {
     __shared__ int wsum[4];
     __shared__ int carry;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int len = lens ? lens[b] : T;
-    const float al = alpha ? *alpha : 1.f;
     const float* xb = x + (long long)b * T * C;
-    float* yb = y + (long long)b * T * C;
     if (tid == 0) carry = 0;
     __syncthreads();
     for (int t0 = 0; t0 < T; t0 += 256) {
         const int t = t0 + tid;
-        const bool nz = table && t < T && xb[(long long)t * C] != 0.f;
+        const bool nz = t < T && xb[(long long)t * C] != 0.f;
         const unsigned long long m = __ballot(nz);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wave] = __popcll(m);
         __syncthreads();
         int base = carry;
         for (int w = 0; w < wave; ++w) base += wsum[w];
-        int pos = nz ? base + before + 1 : 0;
-        if (pos >= n_pos) pos = 0;   // cannot happen when n_pos > T; keeps the gather in range
+        int p = nz ? base + before + 1 : 0;
+        if (p >= n_pos) p = 0;   // cannot happen when n_pos > T; keeps the gather in range
+        if (t < T) pos[(long long)b * T + t] = p;
         __syncthreads();
         if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        // the 256 frames of this pass, channel-parallel: every wave takes frames, lanes take channels
-        __shared__ int pbuf[256];
-        pbuf[tid] = pos;
-        __syncthreads();
-        const int nt = min(256, T - t0);
-        for (int i = wave; i < nt; i += 4) {
-            const int tt = t0 + i;
-            const bool keep = tt < len;
-            const float* tr = table ? table + (long long)pbuf[i] * C : nullptr;
-            for (int c = lane; c < C; c += 64) {
-                float v = xb[(long long)tt * C + c];
-                if (tr) v = __fadd_rn(v, __fmul_rn(al, tr[c]));   // two roundings, as x + alpha * positions
-                yb[(long long)tt * C + c] = keep ? v : 0.f;
-            }
-        }
         __syncthreads();
     }
 }
-hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const float* alpha, const int* lens, float* y, int B,
-                            int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(fft_input_kernel, dim3(B), dim3(256), 0, s, x, table, n_pos, alpha, lens, y, T, C);
+__global__ __launch_bounds__(256) void fft_input_kernel(const float* x, const float* table, const int* pos, const float* alpha,
+                                                        const int* lens, float* y, long long rows, int T, int C) {
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = (int)(row / T), t = (int)(row % T);
+    const bool keep = !lens || t < lens[b];
+    const float al = alpha ? *alpha : 1.f;
+    const float* tr = table ? table + (long long)pos[row] * C : nullptr;
+    for (int c = lane; c < C; c += 64) {
+        float v = x[row * C + c];
+        if (tr) v = __fadd_rn(v, __fmul_rn(al, tr[c]));   // two roundings, as x + alpha * positions
+        y[row * C + c] = keep ? v : 0.f;
+    }
+}
+hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const float* alpha, const int* lens, int* pos_scratch,
+                            float* y, int B, int T, int C, hipStream_t s) {
+    const long long rows = (long long)B * T;
+    if (table) hipLaunchKernelGGL(fft_positions_kernel, dim3(B), dim3(256), 0, s, x, pos_scratch, n_pos, T, C);
+    hipLaunchKernelGGL(fft_input_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, table, pos_scratch, alpha, lens, y, rows, T, C);
     return hipGetLastError();
 }
 
@@ -720,12 +720,14 @@ hipError_t mask_rows_launch(const float* x, float* y, const int* lens, int B, in
     return hipGetLastError();
 }
 
+// 64 rows per workgroup, one atomicAdd per workgroup into ilens[b] (zeroed by the launcher)
 __global__ void rowcount_nonzero_kernel(const float* x, int* ilens, int T, int C) {
     __shared__ int cnt;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    for (int t = wave; t < T; t += 4) {
+    const int t1 = min(t0 + 64, T);
+    for (int t = t0 + wave; t < t1; t += 4) {
         const float* r = x + ((long long)b * T + t) * C;
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += fabsf(r[c]);
@@ -733,10 +735,12 @@ __global__ void rowcount_nonzero_kernel(const float* x, int* ilens, int T, int C
         if (lane == 0 && s != 0.f) atomicAdd(&cnt, 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) ilens[b] = cnt;
+    if (threadIdx.x == 0 && cnt) atomicAdd(ilens + b, cnt);
 }
 hipError_t rowcount_nonzero_launch(const float* x, int* ilens, int B, int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(rowcount_nonzero_kernel, dim3(B), dim3(256), 0, s, x, ilens, T, C);
+    hipError_t e = hipMemsetAsync(ilens, 0, sizeof(int) * B, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rowcount_nonzero_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, ilens, T, C);
     return hipGetLastError();
 }
 
