@@ -110,19 +110,17 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                 const uint4* wh = (const uint4*)p.w_hi + (size_t)g0 * NCT * 64 + lane;
                 const uint4* wl = (const uint4*)p.w_lo + (size_t)g0 * NCT * 64 + lane;
                 int ctc[NT];
-                bool ctv[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    ctv[n] = ct0 + n < NCT;
-                    ctc[n] = ctv[n] ? ct0 + n : NCT - 1;
-                }
+                for (int n = 0; n < NT; ++n) ctc[n] = ct0 + n < NCT ? ct0 + n : NCT - 1;
+                // 32-bit element offsets (a packed layer is far below 2^31 uint4): one s_mul / s_add per prefetch
+                const int tap_stride_i = (int)tap_stride, kg_stride_i = (int)kg_stride;
                 auto load_w = [&](uint4 (&dh)[NT], uint4 (&dl)[NT], int s) {
                     const int sc = s < S ? s : S - 1;
-                    const size_t off = (size_t)(sc / NKG) * tap_stride + (size_t)(sc % NKG) * kg_stride;
+                    const int off = (sc / NKG) * tap_stride_i + (sc % NKG) * kg_stride_i;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        dh[n] = wh[off + (size_t)ctc[n] * 64];
-                        if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[off + (size_t)ctc[n] * 64];
+                        dh[n] = wh[off + ctc[n] * 64];
+                        if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[off + ctc[n] * 64];
                     }
                 };
                 const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * PITCH + (lane >> 5) * (KG / 2) * ES;
@@ -150,11 +148,8 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
                             for (int n = 0; n < NT; ++n) {
-                                uint4 bh = rh[kg % R][n], bl = rl[kg % R][n];
-                                if (!ctv[n]) {
-                                    bh = make_uint4(0, 0, 0, 0);
-                                    bl = make_uint4(0, 0, 0, 0);
-                                }
+                                // (a co-tile past the layer's last one computes on a clamped copy; the epilogue drops it)
+                                const uint4 bh = rh[kg % R][n], bl = rl[kg % R][n];
                                 if constexpr (ENGINE == ENG_F32) {
                                     const f32x4 a = *(const f32x4*)&xh[kg & 1][m];
                                     const f32x4 w = *(const f32x4*)&bh;
