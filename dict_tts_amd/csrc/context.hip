@@ -627,11 +627,15 @@ int run_encoder(dtts_ctx* h, const Encoder& E, float* x, float* hbuf, float* qkv
 }
 
 // WN.forward with x_mask = 1 (modules/commons/wavenet.py:54-78): x is updated in place, `out` receives the skip sum
+// g == null: `cond` already holds the conditioning (the caller computed it)
 int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float* cond, float* acts, float* out, int B,
            int T, hipStream_t s) {
     const int H = W.hidden;
-    ConvParams p = base_params(g, g_ld, B, T, T, cond, 2 * H * W.layers);
-    LAUNCH(conv1d_launch(W.cond, p, s));
+    ConvParams p;
+    if (g) {
+        p = base_params(g, g_ld, B, T, T, cond, 2 * H * W.layers);
+        LAUNCH(conv1d_launch(W.cond, p, s));
+    }
     for (int i = 0; i < W.layers; ++i) {
         p = base_params(x, H, B, T, T, acts, H);
         p.cond = cond;
@@ -1389,7 +1393,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
     HIPCHK(h->a_dec.reserve(mrows * (size_t)(C + 1 + 2 + 2 * Hd * c.fvae_dec_n_layers + 3 * Hd + 8) * sizeof(float) +
                             qrows * (size_t)(C + c.latent_size + 2 * Hf * c.prior_glow_n_layers + 3 * Hf + 8) * sizeof(float) +
-                            (64 << 10)));
+                            (size_t)B * T_w * 2 * Hd * c.fvae_dec_n_layers * sizeof(float) + (64 << 10)));
     h->m2w = h->a_dec.alloc<int64_t>(mrows);
     h->x_mask = h->a_dec.alloc<float>(mrows);
     if (!h->m2w || !h->x_mask) return fail(h, DTTS_E_NOMEM, "decoder workspace");
@@ -1501,7 +1505,19 @@ int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_s
     // A10: decoder
     p = base_params(z, Z, B, T4, T4, dx, 4 * Hd);  // ConvTranspose1d(k=4,s=4): [B,T4,16] -> [B,T4,4*Hd] == [B,T,Hd]
     LAUNCH(conv1d_launch(h->dec_pre, p, s));
-    int rc = run_wn(h, h->dec_wn, dx, g, C, dcond, dacts, dout, B, T, s);
+    // The decoder's conditioning is a 1x1 convolution of g, and g[b,t] is just word row mel2word[b,t] of the encoder
+    // output (or the zero row): the convolution is applied to the B*T_w word rows (33x fewer than the B*T frames) and its
+    // output gathered by mel2word; frames with mel2word == 0 get conv(0) = bias.  Bit-identical: every output row of this
+    // kernel depends only on its own input row, summed in the same order whatever the tile shape.
+    {
+        const int CW = 2 * Hd * c.fvae_dec_n_layers;
+        float* cond_w = A.alloc<float>((size_t)B * h->T_w * CW);
+        if (!cond_w) return fail(h, DTTS_E_NOMEM, "decoder workspace");
+        p = base_params(h->weo, C, B, h->T_w, h->T_w, cond_w, CW);
+        LAUNCH(conv1d_launch(h->dec_wn.cond, p, s));
+        LAUNCH(expand_launch(cond_w, h->m2w, dcond, nullptr, B, h->T_w, T, CW, s, h->dec_wn.cond.bias));
+    }
+    int rc = run_wn(h, h->dec_wn, dx, nullptr, C, dcond, dacts, dout, B, T, s);
     if (rc) return rc;
     p = base_params(dout, Hd, B, T, T, mel_out, c.audio_num_mel_bins);
     LAUNCH(conv1d_launch(h->dec_out, p, s));

@@ -94,8 +94,9 @@ hipError_t mel2word_fill_launch(const int* starts, const int* total, const int* 
 // teacher-forced: copy [B,T_in] i64 into [B,T_mel] with the same last-column padding; total[b] = #(m2w > 0)
 hipError_t mel2word_copy_launch(const int64_t* src, int64_t* dst, int* total, int B, int T_in, int T_mel, hipStream_t s);
 // x[b,f,:] = m2w[b,f] > 0 ? weo[b, m2w-1, :] : 0 ; x_mask[b,f] = m2w > 0   (model.py:101-107, :53)
+// zero_row: [C] row written where m2w == 0 instead of zeros (null: zeros); x_mask may be null
 hipError_t expand_launch(const float* weo, const int64_t* m2w, float* x, float* x_mask, int B, int T_w, int T_mel, int C,
-                         hipStream_t s);
+                         hipStream_t s, const float* zero_row = nullptr);
 
 // save_wav's sample conversion on the device (utils/audio.py:11-16): per utterance b over its n_b = lens[b] * hop valid
 // samples: norm -> w / max|w|; w * 32767 in fp32; truncating cast to int16.  Samples past n_b are written as 0.

@@ -849,8 +849,8 @@ hipError_t mel2word_copy_launch(const int64_t* src, int64_t* dst, int* total, in
     return hipGetLastError();
 }
 
-__global__ void expand_kernel(const float* weo, const int64_t* m2w, float* x, float* x_mask, int T_w, int T_mel, int C,
-                              int rows) {
+__global__ void expand_kernel(const float* weo, const int64_t* m2w, float* x, float* x_mask, const float* zero_row, int T_w,
+                              int T_mel, int C, int rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int b = row / T_mel;
@@ -859,14 +859,16 @@ __global__ void expand_kernel(const float* weo, const int64_t* m2w, float* x, fl
     if (w > 0 && w <= T_w) {
         const f32x4* src = (const f32x4*)(weo + ((long long)b * T_w + (w - 1)) * C);
         for (int c = lane; c < C / 4; c += 64) dst[c] = src[c];
+    } else if (zero_row) {
+        for (int c = lane; c < C / 4; c += 64) dst[c] = ((const f32x4*)zero_row)[c];
     } else {
         for (int c = lane; c < C / 4; c += 64) dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (lane == 0) x_mask[row] = w > 0 ? 1.f : 0.f;
+    if (x_mask && lane == 0) x_mask[row] = w > 0 ? 1.f : 0.f;
 }
 hipError_t expand_launch(const float* weo, const int64_t* m2w, float* x, float* x_mask, int B, int T_w, int T_mel, int C,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(expand_kernel, dim3((B * T_mel + 3) / 4), dim3(256), 0, s, weo, m2w, x, x_mask, T_w, T_mel, C,
+                         hipStream_t s, const float* zero_row) {
+    hipLaunchKernelGGL(expand_kernel, dim3((B * T_mel + 3) / 4), dim3(256), 0, s, weo, m2w, x, x_mask, zero_row, T_w, T_mel, C,
                        B * T_mel);
     return hipGetLastError();
 }
