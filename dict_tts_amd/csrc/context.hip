@@ -1264,8 +1264,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     const size_t rows = (size_t)B * T_w;
     h->encoded = false;
     HIPCHK(h->a_enc.reserve(rows * (size_t)(12 * C + 3 * C + F + 2 * D + 3 * c.dur_chans + P + 8) * sizeof(float) +
-                            (size_t)B * L_k * T_w * sizeof(float) + (size_t)B * (T_w + 8) * 4 * sizeof(int) + (64 << 10) +
-                            s2pa_scratch_bytes((int)rows, L_k, D)));
+                            (size_t)B * L_k * T_w * sizeof(float) + (size_t)B * (T_w + 8) * 4 * sizeof(int) + (64 << 10)));
     Arena& A = h->a_enc;
     float* x = A.alloc<float>(rows * C);
     float* hb = A.alloc<float>(rows * C);
@@ -1283,7 +1282,6 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     h->dur = A.alloc<float>(rows);
     h->pron_attn = A.alloc<float>(rows * P);
     h->dict_attn = A.alloc<float>((size_t)B * L_k * T_w);
-    char* s2pa_scratch = A.alloc<char>(s2pa_scratch_bytes((int)rows, L_k, D));
     float* d0 = A.alloc<float>(rows * c.dur_chans);
     float* d1 = A.alloc<float>(rows * c.dur_chans);
     h->lens = A.alloc<int>(B);
@@ -1346,7 +1344,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         a.language_zh = c.language_zh;
         {
             Timed tm(h, DTTS_TIMER_S2PA, s);
-            LAUNCH(s2pa_launch(a, s2pa_scratch, s));
+            LAUNCH(s2pa_launch(a, s));
         }
         p = base_params(wv, D, B, T_w, T_w, v, C);
         LAUNCH(conv1d_launch(h->s2_v, p, s));

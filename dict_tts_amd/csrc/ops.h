@@ -57,17 +57,8 @@ struct S2paArgs {
     const int* t_poff;         // [n_entries + 1] pinyin-token offsets
     const int64_t* t_pinyin;   // [sum_P]
     const int64_t* t_pinyin_map;
-    // filled by s2pa_launch from its scratch buffer: per-chunk partial results of the words that are split
-    float* part_v;     // [rows][nch_max][D] weighted value sums (unnormalised)
-    float* part_e;     // [rows][L_k] exp(logit - chunk max) of the live rows
-    float* part_stat;  // [rows][nch_max][2] chunk max, chunk sum
-    int* nch;          // [rows] chunks the word was split into
-    int nch_max;
 };
-constexpr int S2PA_CH = 64;      // live gloss rows one workgroup streams per pass
-constexpr int S2PA_MAXCH = 16;   // L_k <= 1024
-size_t s2pa_scratch_bytes(int rows, int L_k, int D);
-hipError_t s2pa_launch(const S2paArgs& a, void* scratch, hipStream_t s);
+hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s);
 hipError_t max_i64_launch(const int64_t* x, long long n, int* out, hipStream_t s);
 // table mode: out = max over rows of the entry's max pinyin_map (t_pmmax[e]; 1 for entry -1, 0 for -2)
 hipError_t max_entry_pm_launch(const int* entry, const int* t_pmmax, long long n, int* out, hipStream_t s);

@@ -198,7 +198,6 @@ struct S2paShared {
     float sense[16];
     float pw[64];
     int pid[64 + 4];
-    float sc[S2PA_MAXCH];
     int n_live;
 };
 // where one word's rows come from: the collated tensors, or the resident table
@@ -356,73 +355,15 @@ __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, con
     }
 }
 
-// Merge of a split word's per-chunk results: M = max m_c, S = sum s_c exp(m_c - M); weights and value sums are
-// rescaled by exp(m_c - M) / S; then the common tail.  sh.km / sh.idx (s2pa_list) must be in place.  Everything it
-// needs is requested up front (one load latency).
-__device__ __forceinline__ void s2pa_combine(S2paShared& sh, const S2paArgs& a, const S2paPre& pre, int row, int b, int t, int n, int nch,
-                                             int tid) {
-    const int L = a.L_k;
-    __shared__ float stat[2 * S2PA_MAXCH];
-    float st = 0.f;
-    if (tid < 2 * nch) st = a.part_stat[(long long)row * a.nch_max * 2 + tid];
-    float pv[3][4];   // up to 4 chunks (L_k <= 256) prefetched; more are read in the loop below
-    const int npre = min(nch, 4);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            pv[j][c] = (c < npre && tid + j * S2PA_NTHR < a.D) ? a.part_v[((long long)row * a.nch_max + c) * a.D + tid + j * S2PA_NTHR] : 0.f;
-    if (tid < 2 * nch) stat[tid] = st;
-    __syncthreads();
-    if (tid == 0) {
-        if (n > 0) {
-            float M = -3.0e38f, S = 0.f;
-            for (int c = 0; c < nch; ++c) M = fmaxf(M, stat[2 * c]);
-            for (int c = 0; c < nch; ++c) {
-                const float f = expf(stat[2 * c] - M);
-                sh.sc[c] = f;
-                S += stat[2 * c + 1] * f;
-            }
-            for (int c = 0; c < nch; ++c) sh.sc[c] = sh.sc[c] / S;
-        } else {
-            for (int c = 0; c < nch; ++c) sh.sc[c] = 1.f / (float)L;   // all L logits equal: uniform softmax
-        }
-    }
-    for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = n > 0 ? 0.f : 1.f / (float)L;   // masked rows: exp(-1e9 - M) == 0
-    __syncthreads();
-    if (n > 0)
-        for (int i = tid; i < n; i += S2PA_NTHR) {
-            const int l = sh.idx[i];
-            sh.lg[l] = a.part_e[(long long)row * L + l] * sh.sc[i / S2PA_CH];
-        }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int d = tid + j * S2PA_NTHR;
-        if (d < a.D) {
-            float sum = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < npre) sum += pv[j][c] * sh.sc[c];
-            for (int c = 4; c < nch; ++c) sum += a.part_v[((long long)row * a.nch_max + c) * a.D + d] * sh.sc[c];
-            a.wv[(long long)row * a.D + d] = sum;
-        }
-    }
-    __syncthreads();
-    s2pa_tail(sh, a, pre, row, b, t, tid);
-}
-
-// grid (words, chunks): workgroup (row, c) streams the live rows [c * S2PA_CH, (c + 1) * S2PA_CH) of word `row`.
-// A word with at most S2PA_CH live rows (almost all of them) is finished by its c = 0 workgroup; longer ones (the
-// BOS / last rows the collater pads with 148 all-ones key_map entries, the occasional long entry) leave per-chunk
-// partial results (local max, sum, unnormalised weights, weighted value sum) for s2pa_combine_kernel, so that no
-// workgroup streams more than S2PA_CH rows per pass and the launch has no long tail.
+// One workgroup per word.  (Splitting words with many live rows across workgroups, flash-decoding style, was tried:
+// the main kernel drops from 85 to 67 us but the merge pass costs 10 us plus a launch gap, and merging inside the kernel
+// by the chunk that arrives last needs device-scope fences that write back / invalidate a whole L2 on this multi-XCD
+// part - 235 us.  Net zero by the stream's clock, so the simple form stays.)
 __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     __shared__ S2paShared sh;
     constexpr int RU = S2PA_RU;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // row = b * T_w + t.  Workgroups are dispatched in blockIdx order: the high chunks go first (most of them belong to
-    // short words and exit at once), so that the chunks of a long word all start with the bulk instead of queueing behind it
-    const int row = blockIdx.x, c = gridDim.y - 1 - blockIdx.y;
+    const int row = blockIdx.x;  // b * T_w + t
     const int b = row / a.T_w, t = row % a.T_w;
     const int L = a.L_k, D4 = a.D / 4;
     const S2paRow r = s2pa_row(a, row);
@@ -437,20 +378,13 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     // caller whatever the values are, so nothing is read for it
     const bool dead = a.lens && t >= a.lens[b];
     const int n_val = dead ? 0 : (n ? n : r.Lrow);
-    const int nch = max(1, (max(n, n_val) + S2PA_CH - 1) / S2PA_CH);
-    if (c >= nch) return;
-    const bool multi = nch > 1;
-    if (c == 0 && tid == 0) a.nch[row] = nch;
-    const int lo = c * S2PA_CH;
-    const int hi = multi ? min(lo + S2PA_CH, n) : n;            // listed rows [lo, hi): keys
-    const int vhi = multi ? min(lo + S2PA_CH, n_val) : n_val;   // listed rows [lo, vhi): values
     // logits: a wave takes RU listed rows at a time - 12 independent 16-byte loads per lane before the first reduction
-    for (int i = lo + wave * RU; i < hi; i += S2PA_NW * RU) {
+    for (int i = wave * RU; i < n; i += S2PA_NW * RU) {
         f32x4 k[RU][S2PA_DMAX4];
         int lr[RU];
 #pragma unroll
         for (int j = 0; j < RU; ++j) {
-            lr[j] = sh.idx[min(i + j, hi - 1)];
+            lr[j] = sh.idx[min(i + j, n - 1)];
             const f32x4* kr = r.kb + (long long)lr[j] * D4;
 #pragma unroll
             for (int cc = 0; cc < S2PA_DMAX4; ++cc)
@@ -463,50 +397,35 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
             for (int cc = 0; cc < S2PA_DMAX4; ++cc)
                 if (lane + 64 * cc < D4) acc += k[j][cc][0] * q[cc][0] + k[j][cc][1] * q[cc][1] + k[j][cc][2] * q[cc][2] + k[j][cc][3] * q[cc][3];
             acc = wave_sum(acc);
-            if (lane == 0 && i + j < hi) sh.lg[lr[j]] = acc;
+            if (lane == 0 && i + j < n) sh.lg[lr[j]] = acc;
         }
     }
     __syncthreads();
-    float cmx = 0.f, csm = 0.f;
-    if (!multi) {   // softmax over all l
-        float mx = -3.0e38f;
-        for (int l = tid; l < L; l += S2PA_NTHR) mx = fmaxf(mx, sh.lg[l]);
-        mx = s2pa_block_max(sh, mx, tid);
-        float sm = 0.f;
-        for (int l = tid; l < L; l += S2PA_NTHR) {
-            const float e = expf(sh.lg[l] - mx);
-            sh.lg[l] = e;
-            sm += e;
-        }
-        sm = s2pa_block_sum(sh, sm, tid);
-        for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = sh.lg[l] / sm;
-    } else if (n > 0) {   // chunk-local: max / exp / sum over this chunk's live rows only
-        float mx = -3.0e38f;
-        for (int i = lo + tid; i < hi; i += S2PA_NTHR) mx = fmaxf(mx, sh.lg[sh.idx[i]]);
-        cmx = s2pa_block_max(sh, mx, tid);
-        float sm = 0.f;
-        for (int i = lo + tid; i < hi; i += S2PA_NTHR) {
-            const float e = expf(sh.lg[sh.idx[i]] - cmx);
-            sh.lg[sh.idx[i]] = e;
-            sm += e;
-        }
-        csm = s2pa_block_sum(sh, sm, tid);
-    } else {   // no live row: every value row has the same weight (fixed up by the combine kernel)
-        for (int i = lo + tid; i < vhi; i += S2PA_NTHR) sh.lg[sh.idx[i]] = 1.f;
+    // softmax over l
+    float mx = -3.0e38f;
+    for (int l = tid; l < L; l += S2PA_NTHR) mx = fmaxf(mx, sh.lg[l]);
+    mx = s2pa_block_max(sh, mx, tid);
+    float sm = 0.f;
+    for (int l = tid; l < L; l += S2PA_NTHR) {
+        const float e = expf(sh.lg[l] - mx);
+        sh.lg[l] = e;
+        sm += e;
     }
+    sm = s2pa_block_sum(sh, sm, tid);
+    for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = sh.lg[l] / sm;
     __syncthreads();
     // weighted sum of the value rows (masked rows have weight exactly 0 and rows >= Lrow are zero vectors: only the
-    // listed rows contribute)
+    // listed rows contribute; with no live row the softmax is uniform and the list holds every row)
     f32x4 acc[S2PA_DMAX4];
 #pragma unroll
     for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = lo + wave * RU; i < vhi; i += S2PA_NW * RU) {
+    for (int i = wave * RU; i < n_val; i += S2PA_NW * RU) {
         f32x4 v[RU][S2PA_DMAX4];
         float w[RU];
 #pragma unroll
         for (int j = 0; j < RU; ++j) {
-            const int l = sh.idx[min(i + j, vhi - 1)];
-            w[j] = i + j < vhi ? sh.lg[l] : 0.f;
+            const int l = sh.idx[min(i + j, n_val - 1)];
+            w[j] = i + j < n_val ? sh.lg[l] : 0.f;
             const f32x4* vr = r.vb + (long long)l * D4;
 #pragma unroll
             for (int cc = 0; cc < S2PA_DMAX4; ++cc)
@@ -521,60 +440,18 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     for (int cc = 0; cc < S2PA_DMAX4; ++cc)
         if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = acc[cc];
     __syncthreads();
-    float* dst = multi ? a.part_v + ((long long)row * a.nch_max + c) * a.D : a.wv + (long long)row * a.D;
     for (int d = tid; d < a.D; d += S2PA_NTHR) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d];
-        dst[d] = sum;
+        a.wv[(long long)row * a.D + d] = sum;
     }
-    if (!multi) {
-        s2pa_tail(sh, a, pre, row, b, t, tid);
-        return;
-    }
-    if (n > 0)
-        for (int i = lo + tid; i < hi; i += S2PA_NTHR) a.part_e[(long long)row * L + sh.idx[i]] = sh.lg[sh.idx[i]];
-    if (tid == 0) {
-        a.part_stat[((long long)row * a.nch_max + c) * 2] = cmx;
-        a.part_stat[((long long)row * a.nch_max + c) * 2 + 1] = csm;
-    }
+    s2pa_tail(sh, a, pre, row, b, t, tid);
 }
 
-// the merge pass: one workgroup per word, words that were not split exit at once.  (Merging inside s2pa_kernel by the
-// chunk that arrives last needs device-scope release/acquire fences, which write back / invalidate a whole L2 on this
-// multi-XCD part: measured 235 us instead of 67 + 10.)
-__global__ __launch_bounds__(S2PA_NTHR) void s2pa_combine_kernel(const S2paArgs a) {
-    __shared__ S2paShared sh;
-    const int tid = threadIdx.x;
-    const int row = blockIdx.x;
-    const int nch = a.nch[row];
-    if (nch <= 1) return;
-    const S2paRow r = s2pa_row(a, row);
-    const S2paPre pre = s2pa_prefetch(a, r, row, tid);
-    const int n = s2pa_list(sh, r, a.L_k, tid);
-    s2pa_combine(sh, a, pre, row, row / a.T_w, row % a.T_w, n, nch, tid);
-}
-
-size_t s2pa_scratch_bytes(int rows, int L_k, int D) {
-    const size_t nch = (size_t)(L_k + S2PA_CH - 1) / S2PA_CH;
-    return (size_t)rows * (nch * D + L_k + nch * 2 + 1) * sizeof(float) + 1024;
-}
-hipError_t s2pa_launch(const S2paArgs& a0, void* scratch, hipStream_t s) {
-    if (a0.L_k > S2PA_LMAX || a0.D > 768 || (a0.D & 3) || a0.P > 64) return hipErrorInvalidValue;
-    S2paArgs a = a0;
-    const int rows = a.B * a.T_w;
-    a.nch_max = (a.L_k + S2PA_CH - 1) / S2PA_CH;
-    if (a.nch_max > S2PA_MAXCH) return hipErrorInvalidValue;
-    float* f = (float*)scratch;
-    a.part_v = f;
-    f += (size_t)rows * a.nch_max * a.D;
-    a.part_e = f;
-    f += (size_t)rows * a.L_k;
-    a.part_stat = f;
-    f += (size_t)rows * a.nch_max * 2;
-    a.nch = (int*)f;
-    hipLaunchKernelGGL(s2pa_kernel, dim3(rows, a.nch_max), dim3(S2PA_NTHR), 0, s, a);
-    if (a.nch_max > 1) hipLaunchKernelGGL(s2pa_combine_kernel, dim3(rows), dim3(S2PA_NTHR), 0, s, a);
+hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
+    if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(s2pa_kernel, dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
     return hipGetLastError();
 }
 

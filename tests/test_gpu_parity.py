@@ -377,11 +377,10 @@ def test_device_int16_conversion_equals_reference_rule(voc_bf16, norm):
 
 
 @pytest.mark.gpu
-def test_s2pa_split_words_vs_oracle_and_repeatable(acoustic, oracle_sd):
-    """words with more live gloss rows than one workgroup streams (S2PA_CH = 64) are split into chunks whose partial
-    softmax statistics are merged by a second pass: long NON-zero spans (so a stale or missing partial
-    would show), a long fully-masked word (uniform weights over all rows), a word past its utterance's end, chunk
-    boundaries at 64 / 65 / 128 / 129 live rows -- against the oracle, and bit-identical over repeated launches"""
+def test_s2pa_long_words_vs_oracle_and_repeatable(acoustic, oracle_sd):
+    """words with many live gloss rows (64 / 65 / 128 / 129 / 158 of 160, NON-zero glosses so that a missed row would
+    show), a long fully-masked word (uniform weights over all rows, every value row read), a long word past its
+    utterance's end (nothing read) -- against the oracle, and bit-identical over repeated launches"""
     from oracle import dict_tts_ref as ref
     st = synth.biaobei_struct()
     sents = [st["sentences"][i] for i in (2, 5, 9, 14)]
