@@ -480,3 +480,32 @@ def test_fft_blocks_long_batch_vs_oracle_and_missing_weight():
     m2 = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=9, num_heads=2, hparams={})
     with pytest.raises(RuntimeError, match="layers.2.op.ffn.ffn_2.bias"):
         m2.load_state_dict({k: T(v) for k, v in bad.items()})
+
+
+@pytest.mark.gpu
+def test_abi_misuse_fails_loudly(voc_sd):
+    """error convention of the C ABI: negative code + message, surfaced as abi.DttsError; no silent fallback"""
+    from dict_tts_amd import hparams, model
+    m = model.PortaSpeech_dict(hparams={})
+    with pytest.raises(RuntimeError, match="load_state_dict"):
+        m((torch.zeros(1, 3, dtype=torch.int64), None), None, None, None, None, (None,) * 5, infer=True)
+    m.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()})
+    s = torch.cuda.current_stream().cuda_stream
+    buf = torch.zeros(64, device="cuda")
+    with pytest.raises(abi.DttsError, match="before a successful dtts_text2mel_encode"):
+        m.ctx.text2mel_decode(buf.data_ptr(), buf.data_ptr(), s)
+    with pytest.raises(abi.DttsError, match="before encode"):
+        m.ctx.fetch(abi.OUT_DUR, buf.data_ptr(), s)
+    with pytest.raises(abi.DttsError, match="bad argument"):      # L_k beyond the kernel's 1024-row limit
+        m.ctx.text2mel_encode(buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None,
+                              None, 1, 2, 2000, 4, s)
+    with pytest.raises(abi.DttsError, match="dtts_dict_table_upload"):
+        m.ctx.text2mel_encode_ids(buf.data_ptr(), buf.data_ptr(), None, None, 1, 2, 8, 4, s)
+    with pytest.raises(abi.DttsError, match="vocoder weights not finalized"):   # acoustic-only handle has no vocoder
+        m.ctx.hifigan_forward(buf.data_ptr(), None, 1, 4, buf.data_ptr(), s)
+    with pytest.raises(abi.DttsError, match="FFT block weights not finalized"):
+        m.ctx.fft_blocks_forward(buf.data_ptr(), None, None, 0, 1, 4, buf.data_ptr(), s)
+    with pytest.raises(NotImplementedError):
+        m((torch.zeros(1, 3, dtype=torch.int64), None), None, None, None, None, (None,) * 5, infer=False)
+    with pytest.raises(NotImplementedError, match="use_post_glow"):
+        hparams.fill_abi_config(abi.default_config(), {"use_post_glow": True})
