@@ -19,13 +19,14 @@ namespace dtts {
 
 // TT = 128: 3 workgroups per CU; TT = 256: every weight fragment feeds 8 MFMAs instead of 4 (half the weight stream
 // through the texture path, half the halo), 2 workgroups per CU when the LDS tile allows
+// C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
 template <int C, int TT>
-__global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPairParams p) {
+__global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = 1, MH = TT / 128, MTT = MT * MH;
+    constexpr int MT = 4, NT = C / 128, MH = TT / 128, MTT = MT * MH;
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
-    static_assert(NCT == 4, "one co-tile per wave");
+    static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
     const int b = blockIdx.y;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
     const int S = (p.dbg & 1) ? 0 : p.K * NKG;
 
     uint4 ring[4][NT];
-    const size_t wlane = (size_t)wc * 64 + lane;
+    const size_t wlane = (size_t)wc * NT * 64 + lane;   // the wave's first co-tile
     rb_preload<NT>(ring, p.w1 + wlane, NCT * 64);   // c1's first weights fly while the tile is staged
 
     // ---- stage bf16(leaky_relu(x)) for rows [t0 - h2 - h1, t0 - h2 + TT + h1) ; zero outside the utterance.
@@ -70,21 +71,27 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
             }
         }
     }
-    // this lane's bias quads
-    f32x4 bb[4];
+    // this lane's bias quads (channel of accumulator slot 4q+e of co-tile n: (wc * NT + n) * 32 + 8q + 4 (lane >> 5) + e)
+    f32x4 bb[NT][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b1 + wc * 32 + 8 * q + 4 * (lane >> 5));
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b1 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     __syncthreads();
 
     // ---- c1: xt rows r = 0..127  <->  global t0 - h2 + r ; reads staged rows r + tap * d
     f32x16 acc[MTT][NT];
     f32x16 cinit[NT];   // bias pattern of this lane's 16 channel slots: the C operand of every tile's first MFMA
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cinit[0][4 * q + e] = bb[q][e];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bb[q] = *(const f32x4*)(p.b2 + wc * 32 + 8 * q + 4 * (lane >> 5));
+            for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b2 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
     rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
@@ -96,19 +103,23 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
         const int t = t0 - h2 + r;
         const bool inb = t >= 0 && t < len;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint2 pk = make_uint2(pack2bf(lrelu(acc[m][0][4 * q], 0.1f), lrelu(acc[m][0][4 * q + 1], 0.1f)),
-                                  pack2bf(lrelu(acc[m][0][4 * q + 2], 0.1f), lrelu(acc[m][0][4 * q + 3], 0.1f)));
-            if (!inb) pk = make_uint2(0, 0);
-            *(uint2*)(smem + r * PITCH + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
-        }
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk = make_uint2(pack2bf(lrelu(acc[m][n][4 * q], 0.1f), lrelu(acc[m][n][4 * q + 1], 0.1f)),
+                                      pack2bf(lrelu(acc[m][n][4 * q + 2], 0.1f), lrelu(acc[m][n][4 * q + 3], 0.1f)));
+                if (!inb) pk = make_uint2(0, 0);
+                *(uint2*)(smem + r * PITCH + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
+            }
     }
     __syncthreads();
     // ---- c2: output rows o = 0..127 <-> global t0 + o (valid for o < TTe) ; reads xt rows o + tap
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cinit[0][4 * q + e] = bb[q][e];
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
     rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
@@ -128,7 +139,8 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
         const int o = m * 32 + u * RSTEP + r0;
         return o < TTe ? eoff0 + (m * 32 + u * RSTEP) * (C * 4) : (int)0x80000000;
     };
-    u32x4 xin[2][PER], sold[2][PER];
+    constexpr int EB = NT == 1 ? 2 : 1;   // slab reads double-buffered only while the registers allow it
+    u32x4 xin[EB][PER], sold[EB][PER];
     auto fetch = [&](int m, u32x4 (&xi)[PER], u32x4 (&so)[PER]) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -141,20 +153,23 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
 #pragma unroll
     for (int m = 0; m < MTT; ++m) {
         if (m) __syncthreads();
+        if (EB == 1 && m) fetch(m, xin[0], sold[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v;
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[m][0][4 * q + e];
-            *(f32x4*)(smem + (lane & 31) * EP + (wc * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
-        }
-        if (m + 1 < MTT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e];
+                *(f32x4*)(smem + (lane & 31) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+            }
+        if (EB == 2 && m + 1 < MTT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + __builtin_bit_cast(f32x4, xin[m & 1][u]);   // x = xt + x
-            if (p.mode >= 2) o += __builtin_bit_cast(f32x4, sold[m & 1][u]);                                                 // xs += x
+            f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + __builtin_bit_cast(f32x4, xin[m & (EB - 1)][u]);   // x = xt + x
+            if (p.mode >= 2) o += __builtin_bit_cast(f32x4, sold[m & (EB - 1)][u]);                                                 // xs += x
             if (p.mode == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
@@ -169,15 +184,19 @@ __global__ __launch_bounds__(256, TT == 128 ? 3 : 2) void vpair_kernel(const VPa
     }
 }
 
-bool vpair_supported(int C, int K, int dil) { return C == 128 && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5; }
+bool vpair_supported(int C, int K, int dil) {
+    static const bool c256 = !(getenv("DTTS_VPAIR_256") && atoi(getenv("DTTS_VPAIR_256")) == 0);   // A/B switch
+    return (C == 128 || (C == 256 && c256)) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
+}
 
-template <int TT>
+template <int CC, int TT>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
-    constexpr int CC = 128, PITCH = CC * 2 + 16;
+    constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = TT - 2 * h2;
     // staged rows + one spare tap for the activation prefetch; the xt phase needs TT + (K-1) + 1 rows, the epilogue 32 fp32 rows
-    size_t rows = (size_t)TT + 2 * h1 + p.dil + 1 + 8;   // + 8: the staging loop rounds the row count up to its step
+    constexpr int RSTEP = 256 / (CC / 4);                        // the staging loop rounds the row count up to its step
+    size_t rows = (size_t)TT + 2 * h1 + p.dil + 1 + RSTEP;
     if (rows < (size_t)TT + p.K + 1) rows = TT + p.K + 1;
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
@@ -197,11 +216,12 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
 
 hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
     if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
+    if (C == 256) return vpair_launch_tt<256, 128>(p, stream);
     static const int tt = getenv("DTTS_VPAIR_TT") ? atoi(getenv("DTTS_VPAIR_TT")) : 0;   // tuning switch: 128 / 256 / 0 = auto
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + p.dil + 1 + 8;
     const bool big = tt == 256 || (tt == 0 && rows256 * (128 * 2 + 16) * 2 <= 160 * 1024);
-    return big ? vpair_launch_tt<256>(p, stream) : vpair_launch_tt<128>(p, stream);
+    return big ? vpair_launch_tt<128, 256>(p, stream) : vpair_launch_tt<128, 128>(p, stream);
 }
 
 } // namespace dtts
