@@ -338,7 +338,7 @@ def main():
             "audio_samples_per_sec": samples, "rtf": 22050.0 / samples,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "dtts::vconv_kernel<*> + dtts::vpair_kernel<128> + dtts::rblock_kernel<*> (every HifiGAN convolution; 39 launches/forward)",
+                         "kernel": "dtts::vconv_kernel<*> + dtts::vpair_kernel<256|128,*> + dtts::rblock_kernel<*> (every HifiGAN convolution; 30 launches/forward)",
                          "launches": conv_launches,
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "kernel_ms_per_step": conv_ms / max(args.steps, 1),
                          "algorithmic_flop_per_mel_frame": FLOP_PER_FRAME_VOCODER},

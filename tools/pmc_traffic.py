@@ -42,7 +42,7 @@ def main():
     print(json.dumps({
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py, MI355X; FETCH_SIZE doubled "
                   "per MI355X_MICROARCH.md HBM section; units KB; produced by tools/pmc_traffic.py",
-        "kernels": "dtts::vconv_kernel<*> + dtts::vpair_kernel<128> + dtts::rblock_kernel<*> (the HifiGAN convolution family)",
+        "kernels": "dtts::vconv_kernel<*> + dtts::vpair_kernel<*> + dtts::rblock_kernel<*> (the HifiGAN convolution family)",
         "vocoder_forwards_in_profile": forwards, "mel_frames_per_step": frames,
         "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
         "hbm_bytes_per_mel_frame": (rd + wr) / frames, "per_kernel": rows}, indent=1))
