@@ -176,8 +176,141 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* qkv, float* out, 
         if (lane + 64 < dk) dst[lane + 64] = o1[qi] * inv;
     }
 }
+// ---- the same attention on the matrix cores (head size 96): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for both
+// S^T = K Q^T and O = P V, flash-attention style.  Workgroup = 4 waves x 32 queries; keys / values stream through LDS
+// in tiles of 32.  Layout trick: the score tile is computed TRANSPOSED (rows = keys, columns = queries), so that a lane
+// owns one query: its 16 accumulator registers are 16 keys of that query (the other 16 sit in the partner lane +32), the
+// online-softmax statistics are per-lane scalars, and the probabilities are already in the A-operand layout of the
+// P V product (lane = query row, lane half = which key of the pair) - no cross-lane movement for P at all.  Only the
+// per-query rescale factors have to cross lanes (O's rows are queries): 32 floats through a wave-private LDS array.
+typedef __attribute__((ext_vector_type(16))) float f32x16m;
+constexpr int MHX_DK = 96, MHX_KT = 32, MHX_PITCH = MHX_DK * 4 + 16;   // +16 B: rows land on different banks
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const float* qkv, float* out, const int* lens, int T, int C) {
+    __shared__ __attribute__((aligned(16))) char ks[MHX_KT * MHX_PITCH];
+    __shared__ __attribute__((aligned(16))) char vs[MHX_KT * MHX_PITCH];
+    __shared__ __attribute__((aligned(16))) float bc[4][32];   // per-wave broadcast of a per-query scalar
+    constexpr int DK = MHX_DK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int len = lens ? min(max(lens[b], 0), T) : T;
+    const float* base = qkv + (long long)b * T * 3 * C + h * DK;
+    float* ob = out + (long long)b * T * C + h * DK;
+    if (q0 >= len) {   // a tile of padded queries: every caller masks these rows
+        for (int idx = tid; idx < 128 * (DK / 4); idx += 256) {
+            const int i = idx / (DK / 4), c4 = idx % (DK / 4);
+            if (q0 + i < T) *(f32x4*)(ob + (long long)(q0 + i) * C + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const float inv_sqrt = 1.0f / sqrtf((float)DK);
+    const int q = q0 + wave * 32 + x;                // this lane's query
+    // Q fragment: channels 8g + 4 hf .. +3 for g = 0..11 (both operands of an MFMA use the same channel for a lane half,
+    // which is all the contraction needs), zero for queries past the utterance
+    f32x4 qf[DK / 8];
+#pragma unroll
+    for (int g = 0; g < DK / 8; ++g)
+        qf[g] = q < len ? *(const f32x4*)(base + (long long)q * 3 * C + 8 * g + 4 * hf) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16m o[DK / 32];
+#pragma unroll
+    for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    for (int j0 = 0; j0 < len; j0 += MHX_KT) {
+        __syncthreads();
+        for (int idx = tid; idx < MHX_KT * (DK / 4); idx += 256) {   // K / V rows of this tile, zeros past the end
+            const int j = idx / (DK / 4), c4 = idx % (DK / 4);
+            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (j0 + j < len) {
+                const float* r = base + (long long)(j0 + j) * 3 * C + c4 * 4;
+                kv = *(const f32x4*)(r + C);
+                vv = *(const f32x4*)(r + 2 * C);
+            }
+            *(f32x4*)(ks + j * MHX_PITCH + c4 * 16) = kv;
+            *(f32x4*)(vs + j * MHX_PITCH + c4 * 16) = vv;
+        }
+        __syncthreads();
+        // S^T[key][query] = sum_c K[key][c] Q[query][c]
+        f32x16m st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < DK / 8; ++g) {
+            const f32x4 kf = *(const f32x4*)(ks + x * MHX_PITCH + (8 * g + 4 * hf) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], st, 0, 0, 0);
+        }
+        // scores / sqrt(dk), masked_fill(mask == 0, -1e4); register r of this lane is key j0 + (r&3) + 8 (r>>2) + 4 hf
+        float tmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            float sv = st[r] * inv_sqrt;
+            if (!(q < len && j < len)) sv = -1e4f;
+            st[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(st[r] - mn);
+            st[r] = pv;
+            ps += pv;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = mn;
+        // rescale O (its rows are queries): alpha crosses lanes through the wave's LDS array
+        if (hf == 0) bc[wave][x] = alpha;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 al = *(const f32x4*)&bc[wave][8 * r4 + 4 * hf];
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[dt][4 * r4 + e] *= al[e];
+        }
+        // O[query][d] += sum_key P[query][key] V[key][d]: A = P (lane = query, half = key of the pair), B = V
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = (r & 3) + 8 * (r >> 2) + 4 * hf;   // key of this lane half within the tile
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt) {
+                const float vv = *(const float*)(vs + jl * MHX_PITCH + (dt * 32 + x) * 4);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vv, o[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // bc is rewritten next tile
+    }
+    // out = O / l
+    if (hf == 0) bc[wave][x] = 1.0f / l_run;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 il = *(const f32x4*)&bc[wave][8 * r4 + 4 * hf];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qi = q0 + wave * 32 + 8 * r4 + 4 * hf + e;   // query of accumulator register 4 r4 + e
+            if (qi >= T) continue;
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt) ob[(long long)qi * C + dt * 32 + x] = o[dt][4 * r4 + e] * il[e];
+        }
+    }
+}
+
 hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int T, int C, int heads, hipStream_t s) {
     const int dk = C / heads;
+    static const bool use_mfma = !(getenv("DTTS_MHA_MFMA") && atoi(getenv("DTTS_MHA_MFMA")) == 0);   // A/B switch
+    if (dk == MHX_DK && use_mfma) {
+        hipLaunchKernelGGL(mha_mfma_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, lens, T, C);
+        return hipGetLastError();
+    }
     if (dk > MHA_DK_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mha_kernel, dim3((T + MHA_QT - 1) / MHA_QT, heads, B), dim3(256), 0, s, qkv, out, lens, T, C, dk);
     return hipGetLastError();
