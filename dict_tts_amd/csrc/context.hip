@@ -792,6 +792,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 rp.div = (float)nk;
                 rp.slope = last_stage ? 0.01f : 0.1f;
                 rp.Sa = Sa;
+                rp.drop_S = 1;   // after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1] / conv_post)
                 rp.dbg = getenv("DTTS_VCONV_DBG") ? (atoi(getenv("DTTS_VCONV_DBG")) >> 4) & 15 : 0;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
@@ -824,6 +825,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                         vp.y = Sf;
                         vp.mode = j == 0 ? 1 : (j == nk - 1 ? 3 : 2);
                         vp.ya = Sa;
+                        vp.drop_y = 1;   // after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1])
                     }
                     xin = vp.y;
                     Timed tm(h, TV, s);

@@ -17,6 +17,7 @@ struct RBlockParams {
     const int* lens;       // [B] valid rows
     int B, T, K, Kp;
     int mode;              // 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
+    int drop_S;            // mode 2 with Sa: do not write the fp32 xs (nothing reads it after the stage)
     float div, slope;
     int dbg;               // tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };

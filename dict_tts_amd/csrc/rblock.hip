@@ -204,7 +204,8 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, 0);
+            if (!(p.mode == 2 && p.Sa && p.drop_S))   // the stage's consumers read only the bf16 copy: the fp32 sum can stay unwritten
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, 0);
             if (p.mode == 2 && p.Sa) {
                 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};

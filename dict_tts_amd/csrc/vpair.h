@@ -16,6 +16,7 @@ struct VPairParams {
     const int* lens;      // [B] valid rows
     int B, T, K, dil;
     int mode;
+    int drop_y;           // mode 3 with ya: do not write the fp32 result (nothing reads it after the stage)
     float div, slope;
     int dbg;              // tuning ablations (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
 };
