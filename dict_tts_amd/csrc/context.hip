@@ -727,8 +727,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
     bf* Sa = A.alloc<bf>(max_elems);
     bf* melb = A.alloc<bf>((size_t)B * T * melC);
     int* lensS = A.alloc<int>((size_t)(nup + 1) * B);
-    int* mult_d = A.alloc<int>(nup + 1);
-    if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
     {
         StageMult mult;
         mult.m[0] = 1;
@@ -1168,8 +1167,7 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     float* bufT = h->a_voc.alloc<float>(max_elems);
     float* bufS = h->a_voc.alloc<float>(max_elems);
     int* lensS = h->a_voc.alloc<int>((size_t)(nup + 1) * B);
-    int* mult_d = h->a_voc.alloc<int>(nup + 1);
-    if (!bufX || !bufR || !bufT || !bufS || !lensS || !mult_d) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    if (!bufX || !bufR || !bufT || !bufS || !lensS) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
     {
         StageMult mult;
         mult.m[0] = 1;
