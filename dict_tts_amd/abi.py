@@ -19,6 +19,7 @@ TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
 EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
+           "dtts_load_weights", "dtts_text2mel_plan", "dtts_text2mel_forward", "dtts_text2mel_forward_ids",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
            "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
 
@@ -73,6 +74,8 @@ def load_library(path=None):
     lib.dtts_length_regulate.argtypes = [vp, vp, vp, i32, i32, vp, i32, C.POINTER(C.c_int32), vp]
     lib.dtts_hifigan_hop.argtypes = [vp]
     lib.dtts_wav_to_int16.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.dtts_text2mel_forward.argtypes = [vp] + [vp] * 8 + [i32, vp, i32, i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int64), vp, vp, vp]
+    lib.dtts_text2mel_forward_ids.argtypes = [vp] + [vp] * 4 + [i32, vp, i32, i32, i32, i32, i32, vp, i32, C.POINTER(C.c_int64), vp, vp, vp]
     lib.dtts_fft_blocks_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dtts_timer_enable.argtypes = [vp, i32]
     lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -178,6 +181,16 @@ class Context:
 
     def wav_to_int16(self, wav, lens, B, T, norm, out, stream):
         self._chk(self.lib.dtts_wav_to_int16(self.h, wav, lens or None, B, T, int(bool(norm)), out, stream), "dtts_wav_to_int16")
+
+    def text2mel_forward(self, word_tokens, keys, values, key_map, pinyin, pinyin_map, pron_modified, mel2word, z_p, z_cap, B, T_w, L_k,
+                         P, mel_out, mel_cap, pron_attn, dur, stream):
+        """single call: mel2word = (ptr, T_m2w) or None; z_p = device ptr [B,latent,z_cap] or None; returns T_mel"""
+        m2w, t_m2w = mel2word if mel2word else (None, 0)
+        t_mel = C.c_int64(0)
+        self._chk(self.lib.dtts_text2mel_forward(self.h, word_tokens, keys, values, key_map, pinyin, pinyin_map, pron_modified or None,
+                                                 m2w, t_m2w, z_p or None, int(z_cap), B, T_w, L_k, P, mel_out, int(mel_cap),
+                                                 C.byref(t_mel), pron_attn or None, dur or None, stream), "dtts_text2mel_forward")
+        return t_mel.value
 
     def fft_blocks_forward(self, x, lens, pos_table, n_pos, B, T, y, stream):
         self._chk(self.lib.dtts_fft_blocks_forward(self.h, x, lens or None, pos_table or None, int(n_pos), B, T, y, stream),

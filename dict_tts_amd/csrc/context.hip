@@ -131,6 +131,7 @@ struct dtts_ctx {
     // ---- workspaces and per-call state
     Arena a_enc, a_dec, a_voc;
     unsigned* amax_bits = nullptr;  // dtts_wav_to_int16 scratch
+    unsigned long long noise_counter = 0x5EEDull;   // device prior samples (z_p == NULL): one stream per call
     int amax_cap = 0;
     int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
     bool encoded = false;
@@ -1454,10 +1455,12 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
     return DTTS_OK;
 }
 
-int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_stream stream) {
+// z_p: [B][latent][z_ld] (z_ld >= T_mel/4; 0 = exactly T_mel/4) or null = drawn on the device; mel_out: [B][mel_cap][n_mel]
+// (mel_cap >= T_mel; 0 = exactly T_mel), rows >= T_mel are left untouched
+static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out, int mel_cap, dtts_stream stream) {
     if (!h) return DTTS_E_INVAL;
     if (!h->encoded) return fail(h, DTTS_E_STATE, "dtts_text2mel_decode called before a successful dtts_text2mel_encode");
-    if (!z_p || !mel_out) return fail(h, DTTS_E_INVAL, "dtts_text2mel_decode: null argument");
+    if (!mel_out) return fail(h, DTTS_E_INVAL, "dtts_text2mel_decode: null argument");
     hipStream_t s = (hipStream_t)stream;
     const dtts_config& c = h->cfg;
     const int B = h->B, T = h->T_mel, T4 = T / 4, C = c.hidden_size, Z = c.latent_size;
@@ -1486,7 +1489,12 @@ int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_s
     // A8: g_sqz = Conv1d(k=8, s=4, p=2)(g)
     ConvParams p = base_params(g, C, B, T, T4, gs, C);
     LAUNCH(conv1d_launch(h->g_pre, p, s));
-    LAUNCH(transpose_cf_to_cl_launch(z_p, z, B, Z, T4, s));
+    if (z_p) {
+        if (z_ld && z_ld < T4) return fail(h, DTTS_E_INVAL, "prior sample holds %d steps per row, T_mel/4 = %d", z_ld, T4);
+        LAUNCH(transpose_cf_to_cl_launch(z_p, z, B, Z, T4, s, z_ld));
+    } else {
+        LAUNCH(normal_fill_launch(z, (long long)qrows * Z, ++h->noise_counter, s));   // z_p ~ N(0,1) (fvae_semantics.py:110-111)
+    }
     // A9: prior flow, reverse
     for (const Flow& fl : h->flows) {
         p = base_params(z, Z, B, T4, T4, fh, Hf);
@@ -1518,8 +1526,59 @@ int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_s
     int rc = run_wn(h, h->dec_wn, dx, nullptr, C, dcond, dacts, dout, B, T, s);
     if (rc) return rc;
     p = base_params(dout, Hd, B, T, T, mel_out, c.audio_num_mel_bins);
+    if (mel_cap) {
+        if (mel_cap < T) return fail(h, DTTS_E_INVAL, "mel_out holds %d frames per utterance, T_mel = %d", mel_cap, T);
+        p.y_bstride_rows = mel_cap;   // only this layer's output lives in the caller's capacity layout
+    }
     LAUNCH(conv1d_launch(h->dec_out, p, s));
     return DTTS_OK;
+}
+
+int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_stream stream) {
+    if (h && !z_p) return fail(h, DTTS_E_INVAL, "dtts_text2mel_decode: null argument");
+    return decode_impl(h, z_p, 0, mel_out, 0, stream);
+}
+
+// ---- the single-call forms and names of SURVEY.md 8(b)
+int dtts_load_weights(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
+    return dtts_load_weight(h, name, host_ptr, shape, ndim, dtype);
+}
+
+int dtts_text2mel_plan(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values, const float* key_map,
+                       const int64_t* pinyin, const int64_t* pinyin_map, const int64_t* pron_modified, const int64_t* mel2word,
+                       int T_m2w, int B, int T_w, int L_k, int P, int32_t* T_mel_host, dtts_stream stream) {
+    return dtts_text2mel_encode(h, word_tokens, keys, values, key_map, pinyin, pinyin_map, pron_modified, mel2word, T_m2w, B, T_w, L_k,
+                                P, T_mel_host, stream);
+}
+
+static int forward_tail(dtts_handle h, const float* z_p, int z_cap, float* mel_out, int mel_cap, int T_mel, int64_t* T_mel_out,
+                        float* pron_attn, float* dur, dtts_stream stream) {
+    if (T_mel_out) *T_mel_out = T_mel;
+    if (T_mel > mel_cap) return fail(h, DTTS_E_INVAL, "dtts_text2mel_forward: %d frames exceed the capacity %d of mel_out", T_mel, mel_cap);
+    int rc = decode_impl(h, z_p, z_p ? z_cap : 0, mel_out, mel_cap, stream);
+    if (rc == DTTS_OK && pron_attn) rc = dtts_text2mel_fetch(h, DTTS_OUT_PRON_ATTN, pron_attn, stream);
+    if (rc == DTTS_OK && dur) rc = dtts_text2mel_fetch(h, DTTS_OUT_DUR, dur, stream);
+    return rc;
+}
+
+int dtts_text2mel_forward(dtts_handle h, const int64_t* word_tokens, const float* keys, const float* values, const float* key_map,
+                          const int64_t* pinyin, const int64_t* pinyin_map, const int64_t* pron_modified, const int64_t* mel2word,
+                          int T_m2w, const float* z_p, int z_cap, int B, int T_w, int L_k, int P, float* mel_out, int mel_cap,
+                          int64_t* T_mel_out, float* pron_attn, float* dur, dtts_stream stream) {
+    if (h && (!mel_out || mel_cap <= 0)) return fail(h, DTTS_E_INVAL, "dtts_text2mel_forward: bad argument");
+    int32_t T_mel = 0;
+    const int rc = dtts_text2mel_encode(h, word_tokens, keys, values, key_map, pinyin, pinyin_map, pron_modified, mel2word, T_m2w, B,
+                                        T_w, L_k, P, &T_mel, stream);
+    return rc ? rc : forward_tail(h, z_p, z_cap, mel_out, mel_cap, T_mel, T_mel_out, pron_attn, dur, stream);
+}
+
+int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens, const int32_t* entry_ids, const int64_t* pron_modified,
+                              const int64_t* mel2word, int T_m2w, const float* z_p, int z_cap, int B, int T_w, int L_k, int P,
+                              float* mel_out, int mel_cap, int64_t* T_mel_out, float* pron_attn, float* dur, dtts_stream stream) {
+    if (h && (!mel_out || mel_cap <= 0)) return fail(h, DTTS_E_INVAL, "dtts_text2mel_forward_ids: bad argument");
+    int32_t T_mel = 0;
+    const int rc = dtts_text2mel_encode_ids(h, word_tokens, entry_ids, pron_modified, mel2word, T_m2w, B, T_w, L_k, P, &T_mel, stream);
+    return rc ? rc : forward_tail(h, z_p, z_cap, mel_out, mel_cap, T_mel, T_mel_out, pron_attn, dur, stream);
 }
 
 int dtts_text2mel_fetch(dtts_handle h, int what, void* dst, dtts_stream stream) {

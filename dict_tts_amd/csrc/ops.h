@@ -103,6 +103,9 @@ hipError_t fft_input_launch(const float* x, const float* table, int n_pos, const
                             float* y, int B, int T, int C, hipStream_t s);
 
 // [B][C][T] -> [B][T][C] transpose (z_p arrives channels-first as the reference samples it)
-hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s);
+// ldT: time pitch of the source (0 = T)
+hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s, int ldT = 0);
+// y[i] ~ N(0,1), counter-based on (seed, i)
+hipError_t normal_fill_launch(float* y, long long n, unsigned long long seed, hipStream_t s);
 
 } // namespace dtts

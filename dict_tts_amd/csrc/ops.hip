@@ -883,18 +883,41 @@ hipError_t expand_launch(const float* weo, const int64_t* m2w, float* x, float* 
     return hipGetLastError();
 }
 
-__global__ void transpose_cf_to_cl_kernel(const float* x, float* y, int C, int T, long long n) {
+__global__ void transpose_cf_to_cl_kernel(const float* x, float* y, int C, int T, int ldT, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const long long bt = i / C;
         const long long b = bt / T, t = bt % T;
-        y[i] = x[(b * C + c) * T + t];
+        y[i] = x[(b * C + c) * ldT + t];
     }
 }
-hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s) {
+hipError_t transpose_cf_to_cl_launch(const float* x, float* y, int B, int C, int T, hipStream_t s, int ldT) {
     const long long n = (long long)B * C * T;
-    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3(blocks), dim3(256), 0, s, x, y, C, T, n);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3(blocks), dim3(256), 0, s, x, y, C, T, ldT > 0 ? ldT : T, n);
+    return hipGetLastError();
+}
+
+// standard-normal fill (counter-based: splitmix64 of (seed, index) -> two uniforms -> Box-Muller).  Used when the
+// caller passes no prior sample: the reference draws N(0,1) from torch's CPU generator (fvae_semantics.py:110-111), which
+// no device code can reproduce bit for bit; callers that need the reference's noise pass z_p.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void normal_fill_kernel(float* y, long long n, unsigned long long seed) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = splitmix64(seed * 0xD1342543DE82EF95ull + (unsigned long long)i);
+        const float u1 = ((float)(unsigned)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+        const float u2 = ((float)(unsigned)((r >> 8) & 0xFFFFFF) + 0.5f) * (1.0f / 16777216.0f);
+        y[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+}
+hipError_t normal_fill_launch(float* y, long long n, unsigned long long seed, hipStream_t s) {
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(blocks), dim3(256), 0, s, y, n, seed);
     return hipGetLastError();
 }
 

@@ -149,6 +149,30 @@ int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, cons
  */
 int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev, dtts_stream stream);
 
+/*
+ * Single-call forms and names of SURVEY.md 8(b).  dtts_text2mel_forward = dtts_text2mel_encode + dtts_text2mel_decode +
+ * the two fetches every inference consumer needs, with the outputs in CAPACITY layout because T_mel is not known before the
+ * call: mel_out [B, mel_cap, n_mel] (only rows < T_mel of each utterance are written), *T_mel_out (host) = padded frame
+ * count, DTTS_E_INVAL if it exceeds mel_cap; z_p [B, latent, z_cap] with z_cap >= T_mel/4, or NULL = the library draws
+ * N(0,1) on the device (counter-based; the reference's CPU-RNG draw, fvae_semantics.py:110-111, cannot be reproduced bit
+ * for bit, so parity runs pass z_p); pron_attn [B,T_w,P] / dur [B,T_w] may be NULL.  dtts_text2mel_plan is the
+ * two-phase entry (= dtts_text2mel_encode: returns T_mel after the duration kernel); dtts_load_weights = dtts_load_weight.
+ */
+int dtts_load_weights(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+int dtts_text2mel_plan(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+                       const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
+                       const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k, int P,
+                       int32_t* T_mel_host, dtts_stream stream);
+int dtts_text2mel_forward(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+                          const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
+                          const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, const float* z_p_dev, int z_cap,
+                          int B, int T_w, int L_k, int P, float* mel_out_dev, int mel_cap, int64_t* T_mel_out_host,
+                          float* pron_attn_dev, float* dur_dev, dtts_stream stream);
+int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
+                              const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, const float* z_p_dev,
+                              int z_cap, int B, int T_w, int L_k, int P, float* mel_out_dev, int mel_cap, int64_t* T_mel_out_host,
+                              float* pron_attn_dev, float* dur_dev, dtts_stream stream);
+
 /* Copy an intermediate of the last encode/decode into a caller buffer (device to device, on the stream). */
 #define DTTS_OUT_PRON_ATTN 1        /* [B,T_w,P] f32      ret['pron_attn']          */
 #define DTTS_OUT_DUR 2              /* [B,T_w] f32        ret['dur'] (log domain)   */

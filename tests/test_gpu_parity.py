@@ -509,3 +509,50 @@ def test_abi_misuse_fails_loudly(voc_sd):
         m((torch.zeros(1, 3, dtype=torch.int64), None), None, None, None, None, (None,) * 5, infer=False)
     with pytest.raises(NotImplementedError, match="use_post_glow"):
         hparams.fill_abi_config(abi.default_config(), {"use_post_glow": True})
+
+
+@pytest.mark.gpu
+def test_single_call_forward_equals_two_phase(acoustic):
+    """dtts_text2mel_forward (one call, outputs in capacity layout) == encode + decode + fetch, bit for bit on the
+    rows it writes; rows >= T_mel untouched; too small a capacity is an error; z_p = NULL draws N(0,1) on the device"""
+    batch = synth.biaobei_batch(3, 3, gc.SEED)
+    b = {k: T(v).cuda() for k, v in batch.items()}
+    B, T_w = b["word_tokens"].shape
+    L_k, P = b["keys"].shape[2], b["pinyin"].shape[2]
+    s = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: t.data_ptr()
+    m2w_np = synth.teacher_mel2word(batch["word_tokens"], 6, 3)
+    m2w = T(m2w_np).cuda()
+    T_mel = acoustic.ctx.text2mel_encode(ptr(b["word_tokens"]), ptr(b["keys"]), ptr(b["values"]), ptr(b["key_map"]), ptr(b["pinyin"]),
+                                         ptr(b["pinyin_map"]), ptr(b["pron_modified"]), (ptr(m2w), m2w.shape[1]), B, T_w, L_k, P, s)
+    z = T(synth.noise(3, B, T_mel // 4)).cuda()
+    want = torch.empty(B, T_mel, 80, device="cuda")
+    acoustic.ctx.text2mel_decode(ptr(z), ptr(want), s)
+    want_dur = torch.empty(B, T_w, device="cuda")
+    acoustic.ctx.fetch(abi.OUT_DUR, ptr(want_dur), s)
+    cap, zc = T_mel + 37, T_mel // 4 + 5
+    zp = torch.full((B, 16, zc), 99.0, device="cuda")
+    zp[:, :, : T_mel // 4] = z
+    got = torch.full((B, cap, 80), -7.0, device="cuda")
+    pron, dur = torch.empty(B, T_w, P, device="cuda"), torch.empty(B, T_w, device="cuda")
+    t = acoustic.ctx.text2mel_forward(ptr(b["word_tokens"]), ptr(b["keys"]), ptr(b["values"]), ptr(b["key_map"]), ptr(b["pinyin"]),
+                                      ptr(b["pinyin_map"]), ptr(b["pron_modified"]), (ptr(m2w), m2w.shape[1]), ptr(zp), zc, B, T_w, L_k,
+                                      P, ptr(got), cap, ptr(pron), ptr(dur), s)
+    torch.cuda.synchronize()
+    assert t == T_mel
+    assert torch.equal(got[:, :T_mel], want) and bool((got[:, T_mel:] == -7.0).all())
+    assert torch.equal(dur, want_dur)
+    with pytest.raises(abi.DttsError, match="exceed the capacity"):
+        acoustic.ctx.text2mel_forward(ptr(b["word_tokens"]), ptr(b["keys"]), ptr(b["values"]), ptr(b["key_map"]), ptr(b["pinyin"]),
+                                      ptr(b["pinyin_map"]), ptr(b["pron_modified"]), (ptr(m2w), m2w.shape[1]), ptr(zp), zc, B, T_w, L_k,
+                                      P, ptr(got), T_mel - 4, None, None, s)
+    # no prior sample given: drawn on the device; two calls draw different noise, both finite and mel-like
+    a1 = torch.empty(B, cap, 80, device="cuda")
+    a2 = torch.empty(B, cap, 80, device="cuda")
+    for dst in (a1, a2):
+        acoustic.ctx.text2mel_forward(ptr(b["word_tokens"]), ptr(b["keys"]), ptr(b["values"]), ptr(b["key_map"]), ptr(b["pinyin"]),
+                                      ptr(b["pinyin_map"]), ptr(b["pron_modified"]), (ptr(m2w), m2w.shape[1]), None, 0, B, T_w, L_k, P,
+                                      ptr(dst), cap, None, None, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a1[:, :T_mel]).all() and not torch.equal(a1[:, :T_mel], a2[:, :T_mel])
+    assert abs(float(a1[:, :T_mel].std()) - float(want.std())) < 0.25 * float(want.std())
