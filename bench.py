@@ -136,6 +136,7 @@ def main():
     z_all = torch.randn(B, 16, 4096, generator=gen).to(dev)  # prior noise, sliced to T_mel/4 each step
     CAP = 1548                                                # max_frames (egs/egs_bases/tts/base.yaml:45)
     gather_on = world > 1 and not args.no_gather and not one_dev
+    gather_state = [gather_on, None]   # [enabled, reason it was switched off]
     if gather_on:
         mel_pad = torch.zeros(B, CAP, 80, device=dev)
         mel_all = torch.empty(world * B, CAP, 80, device=dev)
@@ -174,13 +175,18 @@ def main():
         lens = torch.empty(B, dtype=torch.int32, device=dev)
         m.ctx.fetch(abi.OUT_MEL_LENS, lens.data_ptr(), stream)
         work = None
-        if gather_on:
+        if gather_state[0]:
             n_cp = min(T_mel, CAP)
             mel_pad[:, :n_cp] = mel[:, :n_cp]
             mel_pad[:, n_cp:].zero_()
             comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                work = dist.all_gather_into_tensor(mel_all, mel_pad, async_op=True)
+            try:
+                with torch.cuda.stream(comm_stream):
+                    work = dist.all_gather_into_tensor(mel_all, mel_pad, async_op=True)
+            except Exception as e:   # the optional collective must not take the measurement down with it
+                gather_state[0] = False
+                gather_state[1] = f"{type(e).__name__}: {e}"[:160]
+                print(f"[bench] rank {rank}: mel all-gather disabled: {gather_state[1]}", file=sys.stderr)
         if pipelined:
             # the acoustic model's launch-bound kernels leave most CUs idle: hand batch i's mel to the vocoder stream
             # and start text->mel of batch i+1 on this one (separate contexts, caller-owned mel/lens/wav buffers)
@@ -331,7 +337,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Biaobei batch=60 per GPU, full Dict-TTS encoder + FVAE decoder + HifiGAN, "
                                    "predicted durations (~22 frames/char)", "utterances_per_gpu": B, "T_w": T_w, "L_k": L_k,
                        "T_mel_padded": T_mel, "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
-                       "parallelism": f"dp{world}" + ("+allgather(mel)" if gather_on else ""),
+                       "parallelism": f"dp{world}" + ("+allgather(mel)" if gather_state[0] else (f" (allgather off: {gather_state[1]})" if gather_state[1] else "")),
                        "streams": "2 (vocoder of batch i overlaps text->mel of batch i+1)" if pipelined else "1",
                        "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision,
                        "dictionary_input": "resident table + ids" if args.dict_table else "keys/values tensors [B,T_w,L_k,768] (reference API)"},
