@@ -556,3 +556,22 @@ def test_single_call_forward_equals_two_phase(acoustic):
     torch.cuda.synchronize()
     assert torch.isfinite(a1[:, :T_mel]).all() and not torch.equal(a1[:, :T_mel], a2[:, :T_mel])
     assert abs(float(a1[:, :T_mel].std()) - float(want.std())) < 0.25 * float(want.std())
+
+
+@pytest.mark.gpu
+def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
+    """the duration path must round exactly as the CPU does (round(exp(dur) - 1) on fp32 values computed by different
+    hardware): eight different batches / gloss embeddings / sentence sets, every mel2word entry equal"""
+    from oracle import dict_tts_ref as ref
+    st = synth.biaobei_struct()
+    for k in range(8):
+        sents = [st["sentences"][(17 * k + 5 * i) % len(st["sentences"])] for i in range(4)]
+        batch = synth.make_batch(sents, 1000 + k, pron_every=2 + k % 3)
+        b = {key: T(v) for key, v in batch.items()}
+        want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                                 b["pron_modified"], z_p=lambda B, T4, k=k: T(synth.noise(50 + k, B, T4)))
+        T_mel = want["mel_out"].shape[1]
+        got = _run(acoustic, batch, z=T(synth.noise(50 + k, 4, T_mel // 4)))
+        assert torch.equal(got["mel2word"].cpu(), want["mel2word"]), k
+        assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-5
+        assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
