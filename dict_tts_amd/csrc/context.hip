@@ -753,11 +753,20 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
         const int* lin = lensS + (size_t)i * B;
         const int* lout = lensS + (size_t)(i + 1) * B;
         ch /= 2;
+        // the bf16 leaky_relu copy of the stage input is consumed only by the per-convolution fallback: the fused kernels
+        // (vpair, rblock) read the fp32 stream and round it themselves
+        bool need_xa = false;
+        for (int j = 0; j < nk; ++j) {
+            const auto& c1 = h->rb1[(size_t)i * nk + j];
+            const bool fused_rb = fuse && !h->rbf1[(size_t)i * nk + j].empty();
+            const bool fused_vp = fuse && vpair_supported(ch, c1[0].K, c1[0].dil) && vpair_supported(ch, c1[2].K, c1[2].dil) && c1[0].C_in_pad == ch;
+            need_xa = need_xa || !(fused_rb || fused_vp);
+        }
         {   // ups[i] (polyphase): Sa [B,Tcur,2ch] -> Xf / Xa [B,Tcur,u*ch] == [B,Tcur*u,ch]
             VConvParams p = vparams(h->ups[i], Sa, lin, B, Tcur);
             p.yf = Xf;
             p.ldyf = u * ch;
-            p.ya = Xa;
+            p.ya = need_xa ? Xa : nullptr;
             p.ldya = u * ch;
             p.slope = 0.1f;
             Timed tm(h, TV, s);
