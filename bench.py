@@ -70,7 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=60)
-    ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16")
+    ap.add_argument("--precision", choices=["f16", "bf16", "bf16x3"], default="f16",
+                    help="vocoder arithmetic (include/dicttts_hip.h): f16 = the waveform-exact default")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of mels when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dict-table", action="store_true",
@@ -114,7 +115,7 @@ def main():
     sd_np["dur_predictor.linear.0.bias"] = np.array([DUR_BIAS], np.float32)
     m = model.PortaSpeech_dict(hparams={})
     m.load_state_dict({k: T(v) for k, v in sd_np.items()})
-    prec = abi.VOC_BF16 if args.precision == "bf16" else abi.VOC_BF16X3
+    prec = abi.VOC_PRECISIONS[args.precision]
     voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()},
                           config=synth.hifigan_config(), precision=prec)
     voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
@@ -323,7 +324,7 @@ def main():
         import glob
         tps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # the newest round's measurement
         tp = tps[-1] if tps else ""
-        if args.precision == "bf16" and tp:
+        if args.precision != "bf16x3" and tp:
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_mel_frame"] * (frames_rank / max(args.steps, 1)) / max(conv_launches / max(args.steps, 1), 1)
@@ -332,7 +333,7 @@ def main():
             "metric": "mel-frames/sec, end-to-end text->mel->wav (audio-samples/sec = 256x; RTF reported alongside)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "bf16x3",
+            "dtype": args.precision,
             "data": "synthetic (random-init weights of the real architecture, Biaobei sentence/dictionary structure)",
             "config": {"workload": "BASELINE configs[1]: Biaobei batch=60 per GPU, full Dict-TTS encoder + FVAE decoder + HifiGAN, "
                                    "predicted durations (~22 frames/char)", "utterances_per_gpu": B, "T_w": T_w, "L_k": L_k,

@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdicttts_hip.so")
 
 DTTS_F32, DTTS_I64 = 0, 1
-VOC_BF16, VOC_BF16X3 = 0, 1
+VOC_BF16, VOC_BF16X3, VOC_F16 = 0, 1, 2
+VOC_PRECISIONS = {"f16": VOC_F16, "bf16": VOC_BF16, "bf16x3": VOC_BF16X3}
 PART_ACOUSTIC, PART_VOCODER, PART_FFT = 1, 2, 4
 OUT_PRON_ATTN, OUT_DUR, OUT_MEL2WORD, OUT_DICT_ATTN, OUT_WORD_ENCODER_OUT, OUT_X_MASK, OUT_CONTEXT, OUT_MEL_LENS = range(1, 9)
 TIMER_VOC_CONV, TIMER_S2PA = 1, 2
 
-EXPORTS = ["dtts_default_config", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
+EXPORTS = ["dtts_default_config", "dtts_config_sizeof", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
            "dtts_load_weights", "dtts_text2mel_plan", "dtts_text2mel_forward", "dtts_text2mel_forward_ids",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
@@ -35,7 +36,7 @@ class DttsConfig(C.Structure):
         ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("n_resblock_kernels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
         ("vocoder_precision", C.c_int32), ("fft_layers", C.c_int32), ("fft_kernel_size", C.c_int32),
-        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32)]
+        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32)]
 
 
 class DttsError(RuntimeError):
@@ -58,6 +59,8 @@ def load_library(path=None):
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     lib.dtts_default_config.argtypes = [C.POINTER(DttsConfig)]
     lib.dtts_default_config.restype = None
+    lib.dtts_config_sizeof.argtypes = []
+    lib.dtts_config_sizeof.restype = C.c_int
     lib.dtts_create.argtypes = [C.POINTER(DttsConfig), C.POINTER(vp)]
     lib.dtts_destroy.argtypes = [vp]
     lib.dtts_destroy.restype = None
@@ -86,7 +89,10 @@ def load_library(path=None):
 
 def default_config():
     cfg = DttsConfig()
-    load_library().dtts_default_config(C.byref(cfg))
+    lib = load_library()
+    if lib.dtts_config_sizeof() != C.sizeof(DttsConfig):
+        raise DttsError(f"dtts_config layout mismatch: library {lib.dtts_config_sizeof()} B, abi.DttsConfig {C.sizeof(DttsConfig)} B")
+    lib.dtts_default_config(C.byref(cfg))
     return cfg
 
 

@@ -189,6 +189,25 @@ float bf2f_host(uint16_t hbits) {
     return f;
 }
 
+// fp32 -> IEEE half bits, round-to-nearest-even, saturating at the largest finite half (weights never get there)
+uint16_t f2h_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);            // >= 65520 rounds past the largest finite half: saturate
+    if (a < 0x33000001u) return (uint16_t)sign;                          // <= 2^-25: rounds to zero
+    const int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                            // 24-bit significand
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                          // bits dropped (subnormal halves drop more)
+    const uint32_t half_ulp = 1u << (shift - 1), rem = m & ((1u << shift) - 1);
+    uint32_t q = m >> shift;
+    if (rem > half_ulp || (rem == half_ulp && (q & 1u))) ++q;
+    uint32_t out = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;   // a carry out of the significand bumps the exponent
+    return (uint16_t)(sign | out);
+}
+
 // Pack one convolution into MFMA fragment order and upload it.  getw(co, ci, tap) addresses the LOGICAL
 // weight; bias is in logical channel order.  gate_H > 0: logical C_out = 2*gate_H, packed co-tiles
 // alternate (tanh[32j..32j+32), sigmoid[H+32j..H+32j+32)).
@@ -232,6 +251,7 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
                 const size_t idx = ((((size_t)tap * NG + g) * NCT + ct) * 64 + half * 32 + col) * E + e;
                 const float v = getw(co, ci, tap);
                 if (engine == ENG_F32) wf[idx] = v;
+                else if (engine == ENG_F16) whi[idx] = f2h_host(v);
                 else {
                     const uint16_t hi = f2bf_host(v);
                     whi[idx] = hi;
@@ -481,7 +501,11 @@ int build_acoustic(dtts_ctx* h) {
 int build_vocoder(dtts_ctx* h) {
     Need need{h, ""};
     const dtts_config& c = h->cfg;
-    const int eng = c.vocoder_precision == DTTS_VOC_BF16X3 ? ENG_BF16X3 : ENG_BF16;
+    // DTTS_VOC_F16 (default): the six serial convolutions on bf16 hi/lo split operands, the ResBlocks on fp16 operands
+    if (c.vocoder_precision != DTTS_VOC_BF16 && c.vocoder_precision != DTTS_VOC_BF16X3 && c.vocoder_precision != DTTS_VOC_F16)
+        return fail(h, DTTS_E_INVAL, "vocoder_precision %d is not one of DTTS_VOC_BF16 / _BF16X3 / _F16", c.vocoder_precision);
+    const int eng = c.vocoder_precision == DTTS_VOC_BF16 ? ENG_BF16 : ENG_BF16X3;                                   // serial convolutions
+    const int eng_rb = c.vocoder_precision == DTTS_VOC_F16 ? ENG_F16 : eng;                                         // ResBlock convolutions
     const std::string v = "vocoder.";
     bool ok = pack_plain(h, need, h->conv_pre, eng, v + "conv_pre", 1, 1, 3);
     h->ups.resize(c.n_upsamples);
@@ -501,18 +525,24 @@ int build_vocoder(dtts_ctx* h) {
         for (int mth = 0; ok && mth < 3; ++mth) {
             const int d = c.resblock_dilation_sizes[j][mth];
             const std::string r = v + "resblocks." + std::to_string(i);
-            ok = ok && pack_plain(h, need, h->rb1[i][mth], eng, r + ".convs1." + std::to_string(mth), d, 1, (k * d - d) / 2);
-            ok = ok && pack_plain(h, need, h->rb2[i][mth], eng, r + ".convs2." + std::to_string(mth), 1, 1, (k - 1) / 2);
+            ok = ok && pack_plain(h, need, h->rb1[i][mth], eng_rb, r + ".convs1." + std::to_string(mth), d, 1, (k * d - d) / 2);
+            ok = ok && pack_plain(h, need, h->rb2[i][mth], eng_rb, r + ".convs2." + std::to_string(mth), 1, 1, (k - 1) / 2);
         }
     }
     // fused ResBlock kernel (bf16 mode, narrow stages): the same weights with the tap axis zero padded so that the
     // number of k-steps is a multiple of the register ring depth
     h->rbf1.assign((size_t)c.n_upsamples * nk, {});
     h->rbf2.assign((size_t)c.n_upsamples * nk, {});
-    for (int i = 0; ok && eng == ENG_BF16 && i < c.n_upsamples * nk; ++i) {
+    for (int i = 0; ok && eng_rb != ENG_BF16X3 && i < c.n_upsamples * nk; ++i) {
         const int j = i % nk, k = c.resblock_kernel_sizes[j];
         const int ch = c.upsample_initial_channel >> (i / nk + 1);
-        if (!rblock_supported(ch, k)) continue;
+        if (!rblock_supported(ch, k)) {
+            bool vp = h->rb1[i][0].C_in_pad == ch;
+            for (int mth = 0; mth < 3; ++mth) vp = vp && vpair_supported(ch, k, c.resblock_dilation_sizes[j][mth]);
+            if (eng_rb == ENG_F16 && !vp)
+                return fail(h, DTTS_E_INVAL, "DTTS_VOC_F16 needs ResBlock widths 32/64/128/256 and odd kernels 3..11 (resblock %d: %d channels, k=%d); use DTTS_VOC_BF16X3", i, ch, k);
+            continue;
+        }
         const int kp = rblock_padded_taps(ch, k);
         h->rbf1[i].resize(3);
         h->rbf2[i].resize(3);
@@ -526,7 +556,7 @@ int build_vocoder(dtts_ctx* h) {
                 const float* pw = w->f.data();
                 PackedConv& L = which ? h->rbf2[i][mth] : h->rbf1[i][mth];
                 const int slack = ch >= 64 ? 1 : 2;   // >= 4 zero k-steps behind the last tap: the weight prefetch never clamps
-                ok = pack_conv(h, L, ENG_BF16, ch, ch, kp + slack,
+                ok = pack_conv(h, L, eng_rb, ch, ch, kp + slack,
                                [=](int co, int ci, int tap) { return tap < k ? pw[((size_t)co * ch + ci) * k + tap] : 0.f; }, bias,
                                which ? 1 : c.resblock_dilation_sizes[j][mth], 1, 0);
                 L.K = k;
@@ -667,6 +697,13 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
 // leaky_relu copy the next convolution consumes (written by the producer's epilogue).
 namespace {
 
+// -DDTTS_ABLATE builds: phase-ablation bits for the vocoder kernels, read ONCE when the library is loaded (never per launch)
+#ifdef DTTS_ABLATE
+static const int g_ablate = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
+#else
+constexpr int g_ablate = 0;
+#endif
+
 struct StageMult { int m[9]; };  // cumulative upsampling factor per stage, passed by value (no H2D copy on the stream)
 __global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int T, int n_stage, StageMult mult) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -695,13 +732,27 @@ VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* len
     p.pad = L.pad;
     p.slope = 1.f;
     p.div = 1.f;
-    static const int dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) & 15 : 0;
-    p.dbg = dbg;
+    p.in_slope = 1.f;
+    p.C_in = L.C_in;
+    p.dbg = g_ablate & 15;
+    return p;
+}
+// waveform-exact form: fp32 input [B][T][ld] (leaky_relu(in_slope) applied while staging), hi/lo split operands
+VConvParams vparams_x3(const PackedConv& L, const float* xf, int ld, float in_slope, const int* lens, int B, int T) {
+    VConvParams p = vparams(L, nullptr, lens, B, T);
+    p.xf = xf;
+    p.ldx = ld;
+    p.in_slope = in_slope;
+    p.wlo = (const uint4*)L.w_lo;
     return p;
 }
 
-int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int B, int T, float* wav, hipStream_t s) {
+// exact = DTTS_VOC_F16: fp32 tensors between kernels (no 16-bit copies), serial convolutions on split operands, ResBlock
+// kernels on fp16 operands
+int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, int B, int T, float* wav, hipStream_t s) {
     const dtts_config& c = h->cfg;
+    const bool exact = c.vocoder_precision == DTTS_VOC_F16;
+    const int el = exact ? EL_F16 : EL_BF16;
     const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
     typedef unsigned short bf;
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
@@ -737,10 +788,16 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
     }
     HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
     const int TV = DTTS_TIMER_VOC_CONV;
-    const bool fuse = !(getenv("DTTS_VOC_FUSE") && atoi(getenv("DTTS_VOC_FUSE")) == 0);  // tuning / A-B switch
-    LAUNCH(f32_to_bf16_pad_launch(mel, melb, (long long)B * T, c.audio_num_mel_bins, melC, s));
+    const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)
     int Tcur = T, ch = c.upsample_initial_channel;
-    {   // conv_pre: only its leaky_relu(0.1) bf16 copy is consumed (by ups[0])
+    if (exact) {   // conv_pre: mel fp32 in, fp32 out
+        VConvParams p = vparams_x3(h->conv_pre, mel, c.audio_num_mel_bins, 1.f, lensS, B, T);
+        p.yf = Sf;
+        p.ldyf = ch;
+        Timed tm(h, TV, s);
+        LAUNCH(vconv_launch(p, s));
+    } else {   // conv_pre: only its leaky_relu(0.1) bf16 copy is consumed (by ups[0])
+        LAUNCH(f32_to_bf16_pad_launch(mel, melb, (long long)B * T, c.audio_num_mel_bins, melC, s));
         VConvParams p = vparams(h->conv_pre, melb, lensS, B, T);
         p.ya = Sa;
         p.ldya = ch;
@@ -763,7 +820,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
             need_xa = need_xa || !(fused_rb || fused_vp);
         }
         {   // ups[i] (polyphase): Sa [B,Tcur,2ch] -> Xf / Xa [B,Tcur,u*ch] == [B,Tcur*u,ch]
-            VConvParams p = vparams(h->ups[i], Sa, lin, B, Tcur);
+            VConvParams p = exact ? vparams_x3(h->ups[i], Sf, 2 * ch, 0.1f, lin, B, Tcur) : vparams(h->ups[i], Sa, lin, B, Tcur);
             p.yf = Xf;
             p.ldyf = u * ch;
             p.ya = need_xa ? Xa : nullptr;
@@ -800,9 +857,10 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 if (nk == 1) rp.mode = 2;
                 rp.div = (float)nk;
                 rp.slope = last_stage ? 0.01f : 0.1f;
-                rp.Sa = Sa;
-                rp.drop_S = 1;   // after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1] / conv_post)
-                rp.dbg = getenv("DTTS_VCONV_DBG") ? (atoi(getenv("DTTS_VCONV_DBG")) >> 4) & 15 : 0;
+                rp.Sa = exact ? nullptr : Sa;
+                rp.drop_S = exact ? 0 : 1;   // bf16 mode: after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1] / conv_post)
+                rp.el = el;
+                rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
                 LAUNCH(rblock_launch(rp, ch, s));
@@ -826,15 +884,16 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                     vp.dil = c1[mth].dil;
                     vp.div = (float)nk;
                     vp.slope = last_stage ? 0.01f : 0.1f;
-                    vp.dbg = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) >> 8 : 0;
+                    vp.el = el;
+                    vp.dbg = g_ablate >> 8;
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;
                     } else {
                         vp.y = Sf;
                         vp.mode = j == 0 ? 1 : (j == nk - 1 ? 3 : 2);
-                        vp.ya = Sa;
-                        vp.drop_y = 1;   // after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1])
+                        vp.ya = exact ? nullptr : Sa;
+                        vp.drop_y = exact ? 0 : 1;   // bf16 mode: after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1])
                     }
                     xin = vp.y;
                     Timed tm(h, TV, s);
@@ -842,6 +901,7 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
                 }
                 continue;
             }
+            if (exact) return fail(h, DTTS_E_STATE, "DTTS_VOC_F16: resblock %d has no fused kernel", i * nk + j);   // build_vocoder rejects such configs
             for (int mth = 0; mth < 3; ++mth) {
                 {   // xt = c1(leaky_relu(x)); only leaky_relu(xt) in bf16 is ever consumed
                     VConvParams p = vparams(c1[mth], mth == 0 ? Xa : Ra, lout, B, Tcur);
@@ -882,7 +942,8 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
         }
     }
     {   // wav = tanh(conv_post(leaky_relu(x, 0.01)))
-        VConvParams p = vparams(h->conv_post, Sa, lensS + (size_t)nup * B, B, Tcur);
+        VConvParams p = exact ? vparams_x3(h->conv_post, Sf, ch, 0.01f, lensS + (size_t)nup * B, B, Tcur)
+                              : vparams(h->conv_post, Sa, lensS + (size_t)nup * B, B, Tcur);
         p.yf = wav;
         p.ldyf = 1;
         p.post_tanh = 1;
@@ -898,6 +959,8 @@ int hifigan_forward_bf16(dtts_ctx* h, const float* mel, const int32_t* lens, int
 // C ABI
 // =========================================================================================================
 extern "C" {
+
+int dtts_config_sizeof(void) { return (int)sizeof(dtts_config); }
 
 void dtts_default_config(dtts_config* c) {
     memset(c, 0, sizeof *c);
@@ -938,7 +1001,7 @@ void dtts_default_config(dtts_config* c) {
         c->resblock_dilation_sizes[i][1] = 3;
         c->resblock_dilation_sizes[i][2] = 5;
     }
-    c->vocoder_precision = DTTS_VOC_BF16;
+    c->vocoder_precision = DTTS_VOC_F16;
     c->fft_layers = 4;
     c->fft_kernel_size = 9;
     c->fft_use_pos_embed = 1;
@@ -1159,7 +1222,7 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     hipStream_t s = (hipStream_t)stream;
     const dtts_config& c = h->cfg;
     const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
-    if (c.vocoder_precision == DTTS_VOC_BF16) return hifigan_forward_bf16(h, mel, lens, B, T, wav, s);
+    if (c.vocoder_precision != DTTS_VOC_BF16X3) return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
     {

@@ -13,7 +13,7 @@
 
 namespace dtts {
 
-enum Engine { ENG_F32 = 0, ENG_BF16 = 1, ENG_BF16X3 = 2 };
+enum Engine { ENG_F32 = 0, ENG_BF16 = 1, ENG_BF16X3 = 2, ENG_F16 = 3 };   // ENG_F16: packed for the fused vocoder kernels only (vpair / rblock)
 
 // One output segment of the epilogue: y[b][t][coff + c] = ((acc + bias) + res + res2) / div
 struct ConvSeg {

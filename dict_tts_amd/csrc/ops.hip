@@ -306,8 +306,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* qkv, float* 
 
 hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int T, int C, int heads, hipStream_t s) {
     const int dk = C / heads;
-    static const bool use_mfma = !(getenv("DTTS_MHA_MFMA") && atoi(getenv("DTTS_MHA_MFMA")) == 0);   // A/B switch
-    if (dk == MHX_DK && use_mfma) {
+    if (dk == MHX_DK) {
         hipLaunchKernelGGL(mha_mfma_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, lens, T, C);
         return hipGetLastError();
     }

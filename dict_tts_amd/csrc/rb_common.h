@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "voc_el.h"
+#include "voc_el.h"
 
 namespace dtts {
 
@@ -31,6 +33,43 @@ __device__ __forceinline__ float lrelu(float a, float slope) {
     return r;
 }
 
+// ---- element type of the 16-bit MFMA operands.  EL_BF16: v_mfma_f32_32x32x16_bf16 (8-bit significand); EL_F16:
+// v_mfma_f32_32x32x16_f16 (11-bit significand, same rate) — the ResBlock stages of the waveform-exact vocoder mode.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+template <int EL>
+__device__ __forceinline__ unsigned pack2(float a, float b) {   // two fp32 -> one dword of two 16-bit values, round-to-nearest-even
+    if constexpr (EL == EL_F16) {
+        const f16x2_t v = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);   // v_cvt_pk_f16_f32
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        return pack2bf(a, b);
+    }
+}
+// leaky_relu feeding a 16-bit operand.  fp16 saturates at 65504 instead of overflowing to inf: median(a, a*slope, 65504)
+// = min(max(a, a*slope), 65504) for every a > -655040 — still two instructions (v_mul + v_med3).
+template <int EL>
+__device__ __forceinline__ float lrelu_op(float a, float slope) {
+    if constexpr (EL == EL_F16) return __builtin_amdgcn_fmed3f(a, a * slope, 65504.f);
+    else return lrelu(a, slope);
+}
+template <int EL>
+__device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
+    if constexpr (EL == EL_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Tuning ablations (skip a phase of a kernel) exist only in builds made with -DDTTS_ABLATE; in the release library the
+// tests below are compile-time false and the branches fold away.
+#ifdef DTTS_ABLATE
+#define DTTS_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define DTTS_DBG(p, bit) 0
+#endif
+
 constexpr int RB_GUARD = 40;  // zero rows on both sides of the LDS tile (>= max pad 25 + one padded tap + one prefetched tap, dilation 5)
 
 // acc += W * act, all taps; act is the LDS tile (bf16, pitch PITCH), weights in fragment order [step][co-tile][lane]
@@ -54,7 +93,7 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
 // MH > 1: the wave owns MH * MT row tiles, processed as MH passes of MT tiles per weight fragment (pass h covers rows
 // h * MT * 32 ...): a weight fragment is fetched once per step and used for MH * MT MFMAs, while only 2 * MT activation
 // fragments are live at a time.
-template <int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1>
+template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1>
 __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[2][MT],
                                          const char* act, const uint4* wpf, int xb, int dilP, int g) {
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
@@ -91,13 +130,11 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
                 for (int n = 0; n < NT; ++n) {
                     if constexpr (CINIT) {
                         if (u == 0) {
-                            acc[h * MT + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                *(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[(u * MH + h) & 1][m], cinit[n], 0, 0, 0);
+                            acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[(u * MH + h) & 1][m], cinit[n]);
                             continue;
                         }
                     }
-                    acc[h * MT + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        *(const bf16x8*)&ring[u][n], *(const bf16x8*)&xa[(u * MH + h) & 1][m], acc[h * MT + m][n], 0, 0, 0);
+                    acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[(u * MH + h) & 1][m], acc[h * MT + m][n]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -109,7 +146,7 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
 // ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
 // activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
 // of guard rows, so the prefetches past the last step need no clamping.  CINIT: acc = cinit + W * act (acc not read).
-template <int MT, int NT, int NKG, int PITCH, bool CINIT = false, int MH = 1>
+template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT = false, int MH = 1>
 __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
                                             int S, int dilP, int kg_stride_unused, const f32x16 (*cinit)[NT] = nullptr) {
     constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
@@ -125,7 +162,7 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&
     int s0 = 0;
     if constexpr (CINIT) {
         if (S > 0) {
-            rb_group<MT, NT, NKG, PITCH, true, MH>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
+            rb_group<EL, MT, NT, NKG, PITCH, true, MH>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
             s0 = 4;
             wpf += 4 * KGS;
             if constexpr (NKG >= 4) {
@@ -145,7 +182,7 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&
     }
     for (; s0 < S; s0 += 4) {
         const f32x16(&dummy)[NT] = *(const f32x16(*)[NT])acc[0];
-        rb_group<MT, NT, NKG, PITCH, false, MH>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
+        rb_group<EL, MT, NT, NKG, PITCH, false, MH>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
         wpf += 4 * KGS;
         if constexpr (NKG >= 4) {
             if (++g == GPT) {

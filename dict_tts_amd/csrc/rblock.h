@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "voc_el.h"
+#include "voc_el.h"
 
 namespace dtts {
 
@@ -19,7 +21,8 @@ struct RBlockParams {
     int mode;              // 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
     int drop_S;            // mode 2 with Sa: do not write the fp32 xs (nothing reads it after the stage)
     float div, slope;
-    int dbg;               // tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
+    int el;                // 16-bit operand type: EL_BF16 (rb_common.h) or EL_F16; the packed weights are in that type
+    int dbg;               // -DDTTS_ABLATE builds only; tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };
 
 bool rblock_supported(int C, int K);

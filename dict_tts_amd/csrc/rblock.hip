@@ -15,7 +15,7 @@
 
 namespace dtts {
 
-template <int C, int MT, int NT, int WT, int WC>
+template <int C, int MT, int NT, int WT, int WC, int EL>
 __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams p) {
     static_assert(WC * NT * 32 == C, "channel tiling must cover C");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 ld[m][u] = u32x4{0u, 0u, 0u, 0u};
-                if (!(p.dbg & 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff0 + (u * MT + m) * (32 * C * 4), 0, 0);
+                if (!DTTS_DBG(p, 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff0 + (u * MT + m) * (32 * C * 4), 0, 0);
             }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
     };
     const bool all_inb = base_t >= 0 && base_t + W <= len;   // block-uniform: no row of the tile needs masking
     auto write_act = [&](const f32x16 (&v)[MT][NT]) {
-        if (p.dbg & 8) return;
+        if (DTTS_DBG(p, 8)) return;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = (wt * MT + m) * 32 + (lane & 31);
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    uint2 pk = make_uint2(pack2bf(lrelu(v[m][n][4 * q], 0.1f), lrelu(v[m][n][4 * q + 1], 0.1f)),
-                                          pack2bf(lrelu(v[m][n][4 * q + 2], 0.1f), lrelu(v[m][n][4 * q + 3], 0.1f)));
+                    uint2 pk = make_uint2(pack2<EL>(lrelu_op<EL>(v[m][n][4 * q], 0.1f), lrelu_op<EL>(v[m][n][4 * q + 1], 0.1f)),
+                                          pack2<EL>(lrelu_op<EL>(v[m][n][4 * q + 2], 0.1f), lrelu_op<EL>(v[m][n][4 * q + 3], 0.1f)));
                     if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 
     const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const int kg_stride = (C / 32) * 64;
-    const int S = (p.dbg & 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
+    const int S = DTTS_DBG(p, 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
     const size_t wlane = (size_t)(wc * NT) * 64 + lane;
     uint4 ring[4][NT];
     f32x4 bb[NT][4];   // one live bias set
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
                 for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
         load_bias(bb, p.b2[it]);       // lands while conv1 runs
         const int d = p.dil[it];
-        rb_contract<MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
+        rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, p.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
         write_act(acc);                // xt (bf16, activated) overwrites it
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
         if (it < 2) load_bias(bb, p.b1[it + 1]);
-        rb_contract<MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
+        rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, p.w1[it + 1] + wlane, kg_stride);
         __syncthreads();               // every wave is done reading xt
         if (it < 2) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
         }
     }
 
-    if (p.dbg & 2) {
+    if (DTTS_DBG(p, 2)) {
         if (xr[0][0][0] == 123.456f) p.S[0] = 1.f;
         return;
     }
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
     }
 }
 
-template <int C, int MT, int NT, int WT, int WC>
+template <int C, int MT, int NT, int WT, int WC, int EL>
 static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
     const int H = 6 * (p.K - 1), TT = W - 2 * H;
     if (TT < 32) return hipErrorInvalidValue;
     const size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
-    auto kern = rblock_kernel<C, MT, NT, WT, WC>;
+    auto kern = rblock_kernel<C, MT, NT, WT, WC, EL>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -243,8 +243,9 @@ int rblock_padded_taps(int C, int K) {
 }
 
 hipError_t rblock_launch(const RBlockParams& p, int C, hipStream_t stream) {
-    if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1>(p, stream);   // 512-row tile, 4 waves over time
-    if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2>(p, stream);   // 512-row tile, 8 waves (4 time x 2 channel)
+    const bool h = p.el == EL_F16;
+    if (C == 32) return h ? rb_launch_cfg<32, 4, 1, 4, 1, EL_F16>(p, stream) : rb_launch_cfg<32, 4, 1, 4, 1, EL_BF16>(p, stream);   // 512-row tile, 4 waves over time
+    if (C == 64) return h ? rb_launch_cfg<64, 4, 1, 4, 2, EL_F16>(p, stream) : rb_launch_cfg<64, 4, 1, 4, 2, EL_BF16>(p, stream);   // 512-row tile, 8 waves (4 time x 2 channel)
     return hipErrorInvalidValue;
 }
 

@@ -8,6 +8,10 @@ namespace dtts {
 struct VConvParams {
     const unsigned short* x;  // bf16 [B][T][ldx], already activated; ldx = C_in_pad (multiple of 8)
     int ldx;
+    const float* xf;          // waveform-exact mode (x == null): fp32 [B][T][ldx] NOT activated; leaky_relu(in_slope) + hi/lo split while staging
+    float in_slope;           //   slope of that leaky_relu (1 = identity)
+    int C_in;                 //   valid input channels (multiple of 4; channels C_in..C_in_pad are zero)
+    const uint4* wlo;         //   bf16 lo pack (w - bf16(w)), same layout as w
     const uint4* w;           // packed bf16 weights (context.hip:pack_conv)
     const float* bias;        // [C_out_pad] (zero padded) or null
     const int* lens;          // [B] valid rows (stride-1 convs: input rows == output rows); null -> T
@@ -23,7 +27,7 @@ struct VConvParams {
     int ldres2;
     float div;                // 1 or num_kernels (true division)
     int post_tanh;
-    int dbg;                  // tuning ablations (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging
+    int dbg;                  // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging
 };
 
 hipError_t vconv_launch(const VConvParams& p, hipStream_t stream);

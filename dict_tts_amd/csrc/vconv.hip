@@ -22,14 +22,18 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
-template <int MT, int NT, int WT, int WC, int CK>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConvParams p) {
+// X3: the waveform-exact mode of the six serial convolutions (conv_pre, the upsamplers, conv_post: 3 % of the FLOPs, 87 % of
+// the bf16 rounding noise, tools/precision_sim.py).  The input is the fp32 tensor itself (leaky_relu(in_slope) applied while
+// staging), split into bf16 hi + lo LDS tiles; weights arrive as hi + lo packs; three MFMAs per step: Wlo*Xhi + Whi*Xlo +
+// Whi*Xhi (16-bit significand products, fp32 accumulation).
+template <int MT, int NT, int WT, int WC, int CK, bool X3>
+__global__ __launch_bounds__(256, X3 ? 2 : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
     constexpr int TT = 32 * MT * WT;
     constexpr int CO_T = 32 * NT * WC;
     constexpr int NKG = CK / 16;
-    constexpr int R = NKG < 4 ? NKG : 4;  // weight-fragment ring slots
+    constexpr int R = X3 ? 2 : (NKG < 4 ? NKG : 4);  // weight-fragment ring slots (X3: three MFMAs per fragment pair, one step of prefetch is enough)
     constexpr int PF = R - 1;             // prefetch distance in k-steps
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,6 +57,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const unsigned short* xb = p.x + (long long)b * p.T * p.ldx;
+    const float* xfb = p.xf + (long long)b * p.T * p.ldx;
+    const int lo_off = (TT + p.K * p.dil) * PITCH;   // X3: byte offset of the lo tile (the hi tile incl. its spare tap precedes it)
     const int xoff = ((wt * MT) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;  // B-operand base of this lane
 
     // weight-fragment ring.  One running pointer walks the packed weights PF steps ahead of the MFMAs: +kg_stride per
@@ -61,14 +67,19 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     // tile is staged (L2 latency overlaps the staging loads); the packed buffer has PF+1 steps of slack at its end.
     const size_t kg_stride = (size_t)NCT * 64;
     const size_t tap_jump = (size_t)NG * NCT * 64 - (size_t)NKG * kg_stride;
-    uint4 ring[R][NT];
+    uint4 ring[R][NT], ringl[X3 ? R : 1][NT];
+    const long long wlo_d = X3 ? (const char*)p.wlo - (const char*)p.w : 0;   // the lo pack mirrors the hi pack: one pointer walks both
+    auto wlo = [&](const uint4* q) { return *(const uint4*)((const char*)q + wlo_d); };
     const uint4* wpf = p.w + (size_t)ct0 * 64 + lane;
     auto preload = [&](int ci0) {
         wpf = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) ring[s % R][n] = wpf[n * 64];
+            for (int n = 0; n < NT; ++n) {
+                ring[s % R][n] = wpf[n * 64];
+                if constexpr (X3) ringl[s % R][n] = wlo(wpf + n * 64);
+            }
             wpf += kg_stride;
             if ((s + 1) % NKG == 0) wpf += tap_jump;
         }
@@ -76,7 +87,37 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     preload(0);
     for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
         if (ci0) __syncthreads();
-        if (!(p.dbg & 4)) {   // stage the activation tile: batches of U independent 16 B loads in flight per thread, then the LDS writes
+        if constexpr (X3) {   // fp32 in: leaky_relu, bf16 hi / lo split, two LDS tiles; 4 channels per 16 B load
+            constexpr int U = 4, PIECES = CK / 4;
+            const int total = rows * PIECES;
+            for (int base = tid; base < total; base += 256 * U) {
+                f32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    const int r = idx / PIECES, c = idx % PIECES;
+                    const int t = in0 + r;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < total && t >= 0 && t < len && ci0 + c * 4 < p.C_in) v[u] = *(const f32x4*)(xfb + (long long)t * p.ldx + ci0 + c * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    const int r = idx / PIECES, c = idx % PIECES;
+                    if (idx >= total) continue;
+                    float a[4], lo[4];
+                    unsigned hb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = lrelu(v[u][e], p.in_slope);
+                        hb[e] = rf2bf(a[e]);
+                        lo[e] = a[e] - __builtin_bit_cast(float, hb[e] << 16);
+                    }
+                    *(uint2*)(smem + r * PITCH + c * 8) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+                    *(uint2*)(smem + lo_off + r * PITCH + c * 8) = make_uint2(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]));
+                }
+            }
+        } else if (!DTTS_DBG(p, 4)) {   // stage the activation tile: batches of U independent 16 B loads in flight per thread, then the LDS writes
             constexpr int U = 8, PIECES = CK / 8;
             const int total = rows * PIECES;
             for (int base = tid; base < total; base += 256 * U) {
@@ -99,31 +140,44 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
         }
         __syncthreads();
         // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s
-        uint4 xa[2][MT];
+        uint4 xa[2][MT], xl[X3 ? 2 : 1][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(smem + xoff + m * 32 * PITCH);
-        const int ntap = (p.dbg & 1) ? 0 : p.K;
+        for (int m = 0; m < MT; ++m) {
+            xa[0][m] = *(const uint4*)(smem + xoff + m * 32 * PITCH);
+            if constexpr (X3) xl[0][m] = *(const uint4*)(smem + lo_off + xoff + m * 32 * PITCH);
+        }
+        const int ntap = DTTS_DBG(p, 1) ? 0 : p.K;
         const int dilP = p.dil * PITCH;
         int arow = xoff;
         for (int tap = 0; tap < ntap; ++tap) {
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) ring[(kg + PF) % R][n] = wpf[n * 64];   // step s + PF
+                for (int n = 0; n < NT; ++n) {   // step s + PF
+                    ring[(kg + PF) % R][n] = wpf[n * 64];
+                    if constexpr (X3) ringl[(kg + PF) % R][n] = wlo(wpf + n * 64);
+                }
                 wpf += kg_stride;
                 if ((kg + PF + 1) % NKG == 0) wpf += tap_jump;
                 {
                     const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow + dilP;   // LDS tile has one spare tap of rows
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
+                    for (int m = 0; m < MT; ++m) {
+                        xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
+                        if constexpr (X3) xl[(kg + 1) & 1][m] = *(const uint4*)(smem + lo_off + nxt + m * 32 * PITCH);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // the prefetches above stay above this step's MFMAs
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&ring[kg % R][n],
-                                                                            *(const bf16x8*)&xa[kg & 1][m], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) {
+                        if constexpr (X3) {   // the two small products first
+                            acc[m][n] = mfma16<EL_BF16>(ringl[kg % R][n], xa[kg & 1][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xl[kg & 1][m], acc[m][n]);
+                        }
+                        acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xa[kg & 1][m], acc[m][n]);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
             arow += dilP;
@@ -131,7 +185,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
         if (ci0 + CK < p.C_in_pad) preload(ci0 + CK);
     }
 
-    if (p.dbg & 2) {
+    if (DTTS_DBG(p, 2)) {
         if (acc[0][0][0] == 123.456f) p.yf[0] = 1.f;
         return;
     }
@@ -226,14 +280,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void vconv_kernel(const VConv
     }
 }
 
-template <int MT, int NT, int WT, int WC, int CK>
-static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
+template <int MT, int NT, int WT, int WC, int CK, bool X3>
+static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
     constexpr int PITCH = CK * 2 + 16, TT = 32 * MT * WT, CO_T = 32 * NT * WC;
     const int rows = TT + p.K * p.dil;   // incl. one spare tap for the activation-fragment prefetch past the last step
-    size_t lds = (size_t)rows * PITCH;
+    size_t lds = (size_t)rows * PITCH * (X3 ? 2 : 1);
     const size_t ep = (size_t)WT * 32 * (CO_T * 4 + 16);
     if (ep > lds) lds = ep;
-    auto kern = vconv_kernel<MT, NT, WT, WC, CK>;
+    auto kern = vconv_kernel<MT, NT, WT, WC, CK, X3>;
     static size_t configured = 0;
     if (lds > 65536 && lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -244,6 +298,15 @@ static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
     dim3 grid((p.T + TT - 1) / TT, p.C_out_pad / CO_T, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
+}
+
+template <int MT, int NT, int WT, int WC, int CK>
+static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
+    if (p.xf) {
+        if (!p.wlo || p.ya) return hipErrorInvalidValue;
+        return vlaunch_x<MT, NT, WT, WC, CK, true>(p, stream);
+    }
+    return vlaunch_x<MT, NT, WT, WC, CK, false>(p, stream);
 }
 
 hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {

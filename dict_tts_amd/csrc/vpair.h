@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "voc_el.h"
+#include "voc_el.h"
 
 namespace dtts {
 
@@ -18,7 +20,8 @@ struct VPairParams {
     int mode;
     int drop_y;           // mode 3 with ya: do not write the fp32 result (nothing reads it after the stage)
     float div, slope;
-    int dbg;              // tuning ablations (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
+    int el;               // 16-bit operand type of both convolutions: EL_BF16 (rb_common.h) or EL_F16; w1 / w2 are packed in that type
+    int dbg;              // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
 };
 
 bool vpair_supported(int C, int K, int dil);

@@ -20,7 +20,7 @@ namespace dtts {
 // TT = 128: 3 workgroups per CU; TT = 256: every weight fragment feeds 8 MFMAs instead of 4 (half the weight stream
 // through the texture path, half the halo), 2 workgroups per CU when the LDS tile allows
 // C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
-template <int C, int TT>
+template <int C, int TT, int EL>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 4, NT = C / 128, MH = TT / 128, MTT = MT * MH;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     const int len = p.lens ? p.lens[b] : p.T;
     if (t0 >= len) return;
     const long long brow = (long long)b * p.T;
-    const int S = (p.dbg & 1) ? 0 : p.K * NKG;
+    const int S = DTTS_DBG(p, 1) ? 0 : p.K * NKG;
 
     uint4 ring[4][NT];
     const size_t wlane = (size_t)wc * NT * 64 + lane;   // the wave's first co-tile
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     const int c4 = tid % F4, r0 = tid / F4;
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
-    if (!(p.dbg & 4)) {
+    if (!DTTS_DBG(p, 4)) {
         constexpr int U = 12;                       // independent loads in flight per thread and batch
         const int nk = (arows + RSTEP - 1) / RSTEP;
         const int voff0 = ((a0 + r0) * C + c4 * 4) * 4;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
                 if (kb + u >= nk) continue;
                 const f32x4 f = __builtin_bit_cast(f32x4, v[u]);
                 *(uint2*)(lrow + (kb + u) * (RSTEP * PITCH)) =
-                    make_uint2(pack2bf(lrelu(f[0], 0.1f), lrelu(f[1], 0.1f)), pack2bf(lrelu(f[2], 0.1f), lrelu(f[3], 0.1f)));
+                    make_uint2(pack2<EL>(lrelu_op<EL>(f[0], 0.1f), lrelu_op<EL>(f[1], 0.1f)), pack2<EL>(lrelu_op<EL>(f[2], 0.1f), lrelu_op<EL>(f[3], 0.1f)));
             }
         }
     }
@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 #pragma unroll
         for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b2 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
-    rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
+    rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
     __syncthreads();   // every wave is done reading the x tile
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
 #pragma unroll
-    for (int m = 0; m < ((p.dbg & 8) ? 0 : MTT); ++m) {
+    for (int m = 0; m < (DTTS_DBG(p, 8) ? 0 : MTT); ++m) {
         const int r = m * 32 + (lane & 31);
         const int t = t0 - h2 + r;
         const bool inb = t >= 0 && t < len;
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint2 pk = make_uint2(pack2bf(lrelu(acc[m][n][4 * q], 0.1f), lrelu(acc[m][n][4 * q + 1], 0.1f)),
-                                      pack2bf(lrelu(acc[m][n][4 * q + 2], 0.1f), lrelu(acc[m][n][4 * q + 3], 0.1f)));
+                uint2 pk = make_uint2(pack2<EL>(lrelu_op<EL>(acc[m][n][4 * q], 0.1f), lrelu_op<EL>(acc[m][n][4 * q + 1], 0.1f)),
+                                      pack2<EL>(lrelu_op<EL>(acc[m][n][4 * q + 2], 0.1f), lrelu_op<EL>(acc[m][n][4 * q + 3], 0.1f)));
                 if (!inb) pk = make_uint2(0, 0);
                 *(uint2*)(smem + r * PITCH + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
             }
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
-    rb_contract<MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
+    rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
-    if (p.dbg & 2) {
+    if (DTTS_DBG(p, 2)) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
         return;
     }
@@ -186,11 +186,10 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 }
 
 bool vpair_supported(int C, int K, int dil) {
-    static const bool c256 = !(getenv("DTTS_VPAIR_256") && atoi(getenv("DTTS_VPAIR_256")) == 0);   // A/B switch
-    return (C == 128 || (C == 256 && c256)) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
+    return (C == 128 || C == 256) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
 }
 
-template <int CC, int TT>
+template <int CC, int TT, int EL>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
@@ -202,8 +201,7 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
-    if (const char* e = getenv("DTTS_VPAIR_LDS")) lds = std::max<size_t>(lds, (size_t)atoi(e) * 1024);  // occupancy experiment
-    auto kern = vpair_kernel<CC, TT>;
+    auto kern = vpair_kernel<CC, TT, EL>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -215,14 +213,18 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
-    if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
-    if (C == 256) return vpair_launch_tt<256, 128>(p, stream);
-    static const int tt = getenv("DTTS_VPAIR_TT") ? atoi(getenv("DTTS_VPAIR_TT")) : 0;   // tuning switch: 128 / 256 / 0 = auto
+template <int EL>
+static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t stream) {
+    if (C == 256) return vpair_launch_tt<256, 128, EL>(p, stream);
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + p.dil + 1 + 8;
-    const bool big = tt == 256 || (tt == 0 && rows256 * (128 * 2 + 16) * 2 <= 160 * 1024);
-    return big ? vpair_launch_tt<128, 256>(p, stream) : vpair_launch_tt<128, 128>(p, stream);
+    const bool big = rows256 * (128 * 2 + 16) * 2 <= 160 * 1024;
+    return big ? vpair_launch_tt<128, 256, EL>(p, stream) : vpair_launch_tt<128, 128, EL>(p, stream);
+}
+
+hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
+    if (!vpair_supported(C, p.K, p.dil)) return hipErrorInvalidValue;
+    return p.el == EL_F16 ? vpair_launch_el<EL_F16>(p, C, stream) : vpair_launch_el<EL_BF16>(p, C, stream);
 }
 
 } // namespace dtts

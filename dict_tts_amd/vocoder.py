@@ -60,7 +60,7 @@ def find_vocoder_checkpoint(base_dir):
 class HifiGAN:
     """Same contract as the reference class: ``spec2wav(mel[T,80], **ignored) -> np.float32[T*hop]``."""
 
-    def __init__(self, state_dict=None, config=None, precision=None, ctx=None):
+    def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False):
         if state_dict is None:
             config, state_dict = find_vocoder_checkpoint(hparams["vocoder_ckpt"])
         self.config = {**HIFIGAN_DEFAULTS, **(config or {})}
@@ -68,9 +68,13 @@ class HifiGAN:
             raise abi.DttsError("dict_tts_amd.vocoder.HifiGAN needs a ROCm GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
         if precision is None:
-            precision = {"bf16": abi.VOC_BF16, "bf16x3": abi.VOC_BF16X3}[os.environ.get("DTTS_VOCODER_PRECISION", "bf16")]
+            precision = abi.VOC_PRECISIONS[os.environ.get("DTTS_VOCODER_PRECISION", "f16")]   # f16 = the waveform-exact default
+        elif isinstance(precision, str):
+            precision = abi.VOC_PRECISIONS[precision]
+        self.precision = precision
         if ctx is None:
             cfg = fill_abi_config(abi.default_config(), None, self.config, vocoder_precision=precision)
+            cfg.vocoder_unfused = 1 if unfused else 0   # testing aid (bf16 mode): one kernel per convolution
             ctx = abi.Context(cfg)
         self.ctx = ctx
         self.ctx.load_state_dict("vocoder", state_dict)

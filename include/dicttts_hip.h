@@ -37,9 +37,16 @@ typedef void* dtts_stream; /* hipStream_t */
 #define DTTS_F32 0
 #define DTTS_I64 1
 
-/* vocoder arithmetic: bf16 MFMA operands with fp32 accumulation, or bf16x3 split operands (fp32-class) */
+/* vocoder arithmetic (fp32 accumulation and an fp32 residual stream in every mode).
+ *   DTTS_VOC_F16 (default): the fused kernels with fp16 MFMA operands in the ResBlocks and bf16 hi/lo split operands (three
+ *     products) in the six serial convolutions (conv_pre, upsamplers, conv_post: 3 % of the FLOPs but 87 % of the 16-bit
+ *     rounding noise, tools/precision_sim.py) — waveform RMS error vs the fp32 reference ~5e-5 (gate 1e-4);
+ *     activations saturate at the fp16 maximum 65504.
+ *   DTTS_VOC_BF16: the same kernels on bf16 operands throughout — RMS error ~1e-3 (fails the waveform gate), a few % faster.
+ *   DTTS_VOC_BF16X3: every convolution on split operands on the generic kernel — fp32-class (~2e-6), several times slower. */
 #define DTTS_VOC_BF16 0
 #define DTTS_VOC_BF16X3 1
+#define DTTS_VOC_F16 2
 
 /* Model hyper-parameters.  Field <- reference hparams key (resolved values, SURVEY.md §5 "Config / flags"). */
 typedef struct dtts_config {
@@ -74,16 +81,19 @@ typedef struct dtts_config {
     int32_t n_resblock_kernels;       /* 3   */
     int32_t resblock_kernel_sizes[4]; /* 3,7,11 */
     int32_t resblock_dilation_sizes[4][3]; /* (1,3,5) x3 */
-    int32_t vocoder_precision;        /* DTTS_VOC_BF16 | DTTS_VOC_BF16X3 */
+    int32_t vocoder_precision;        /* DTTS_VOC_F16 (default) | DTTS_VOC_BF16 | DTTS_VOC_BF16X3 */
     /* FFT block stack (FFTBlocks, modules/fastspeech/tts_modules.py:458-493); width = hidden_size, heads = num_heads */
     int32_t fft_layers;               /* dec_layers 4                          egs/egs_bases/tts/base.yaml:68 */
     int32_t fft_kernel_size;          /* dec_ffn_kernel_size 9                 base.yaml:72                   */
     int32_t fft_use_pos_embed;        /* FFTBlocks(use_pos_embed=True)                                        */
     int32_t fft_use_last_norm;        /* FFTBlocks(use_last_norm=True)                                        */
+    int32_t vocoder_unfused;          /* testing aid, DTTS_VOC_BF16 only: 1 = one kernel per convolution instead of the fused ResBlock kernels */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
 void dtts_default_config(dtts_config* cfg);
+/* sizeof(dtts_config) as this library was compiled: a binding checks its own mirror of the struct against it. */
+int dtts_config_sizeof(void);
 
 /* Create / destroy a context on the current HIP device. */
 int dtts_create(const dtts_config* cfg, dtts_handle* out);

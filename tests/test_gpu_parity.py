@@ -1,7 +1,8 @@
 """GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI via the Python shims,
 against (a) the golden fixtures produced by the REFERENCE implementation and (b) the CPU oracle on the same
 seeded inputs.  Tolerances are BASELINE.json's: mel max-abs <= 1e-3, integer durations exact, waveform
-|RMS(gpu) - RMS(ref)| <= 1e-4 (plus RMS(gpu - ref) <= 1e-4 for the fp32-class vocoder mode), decoded pinyin identical."""
+RMS(gpu - ref) <= 1e-4 AND |RMS(gpu) - RMS(ref)| <= 1e-4 for the default vocoder mode (DTTS_VOC_F16, the one bench.py
+measures), decoded pinyin identical.  The all-bf16 mode is held to its own, looser, documented bound."""
 import os
 
 import numpy as np
@@ -47,8 +48,28 @@ def _vocoder(voc_sd, precision):
 
 
 @pytest.fixture(scope="module")
+def voc(voc_sd):
+    """the default (and benched) mode: fp16 ResBlock operands + split-operand serial convolutions"""
+    v = _vocoder(voc_sd, None)
+    assert v.precision == abi.VOC_F16
+    return v
+
+
+@pytest.fixture(scope="module")
 def voc_bf16(voc_sd):
     return _vocoder(voc_sd, abi.VOC_BF16)
+
+
+@pytest.fixture(scope="module")
+def voc_bf16_unfused(voc_sd):
+    from dict_tts_amd import vocoder
+    return vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision=abi.VOC_BF16, unfused=True)
+
+
+def wave_gate(w, ref):
+    """BASELINE.md §4 / SURVEY §8d: RMS(gpu - ref) and |RMS(gpu) - RMS(ref)| both <= 1e-4"""
+    assert w.shape == ref.shape
+    assert rms(w - ref) <= 1e-4 and abs(rms(w) - rms(ref)) <= 1e-4, (rms(w - ref), rms(w), rms(ref))
 
 
 @pytest.fixture(scope="module")
@@ -158,10 +179,14 @@ def test_length_regulator_device_vs_reference_golden(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ vocoder
-def test_g6_hifigan_vs_reference_golden(voc_bf16, voc_x3, golden_dir):
+def test_g6_hifigan_vs_reference_golden(voc, voc_bf16, voc_x3, golden_dir):
     g = np.load(os.path.join(golden_dir, "g6_hifigan.npz"))
     mel = gc.g6_mel()
     ref_wav = g["wav"]
+    w = voc.spec2wav(mel)
+    assert w.shape == (32 * 256,)
+    wave_gate(w, ref_wav)                                   # the default mode meets the full waveform gate
+    assert np.abs(w - ref_wav).max() <= 1e-3
     w3 = voc_x3.spec2wav(mel)
     assert w3.shape == ref_wav.shape == (32 * 256,)
     assert rms(w3 - ref_wav) <= 1e-4 and abs(rms(w3) - rms(ref_wav)) <= 1e-4, (rms(w3 - ref_wav), rms(w3), rms(ref_wav))
@@ -171,7 +196,7 @@ def test_g6_hifigan_vs_reference_golden(voc_bf16, voc_x3, golden_dir):
     assert rms(w1 - ref_wav) <= 0.02 * rms(ref_wav), rms(w1 - ref_wav) / rms(ref_wav)   # bf16 operands: ~1 % noise
 
 
-def test_hifigan_ragged_batch_equals_per_utterance_oracle(voc_x3, voc_bf16, oracle_voc_sd):
+def test_hifigan_ragged_batch_equals_per_utterance_oracle(voc, voc_x3, voc_bf16, oracle_voc_sd):
     """spec2wav_batch(list) == the reference's one-utterance-per-call spec2wav for every item (zero padding at the
     utterance end, not the batch end); lengths straddle the time-tile sizes"""
     from oracle import hifigan_ref as href
@@ -180,17 +205,20 @@ def test_hifigan_ragged_batch_equals_per_utterance_oracle(voc_x3, voc_bf16, orac
     want = [href.spec2wav(oracle_voc_sd, synth.hifigan_config(), m).numpy() for m in mels]
     got3 = voc_x3.spec2wav_batch(mels)
     got1 = voc_bf16.spec2wav_batch(mels)
-    for w, a, b, n in zip(want, got3, got1, lens):
+    got = voc.spec2wav_batch(mels)
+    for w, a, b, g, n in zip(want, got3, got1, got, lens):
         assert a.shape == w.shape == (n * 256,)
+        wave_gate(g, w)
         assert rms(a - w) <= 1e-4, rms(a - w)
         assert abs(rms(b) - rms(w)) <= 1e-4
     # samples past an utterance's end are zero in the batched output
-    full = voc_x3.forward_batch(torch.stack([T(np.pad(m, ((0, 64 - m.shape[0]), (0, 0)))) for m in mels]).cuda(),
+    full = voc.forward_batch(torch.stack([T(np.pad(m, ((0, 64 - m.shape[0]), (0, 0)))) for m in mels]).cuda(),
                                 torch.tensor(lens, dtype=torch.int32))
     assert float(full[0, 5 * 256:].abs().max()) == 0.0
 
 
-def test_hifigan_linearity_free_properties_long(voc_bf16):
+def test_hifigan_linearity_free_properties_long(voc):
+    voc_bf16 = voc
     """size-independent properties at a realistic length (400 frames): determinism, finite output in (-1, 1),
     and shift-consistency — the middle of the utterance does not depend on what is 200 frames away"""
     mel = synth.random_mel(5, 400, "long")
@@ -215,7 +243,7 @@ def test_missing_weight_fails_loudly(voc_sd):
         ctx.text2mel_decode(1, 1, None)
 
 
-def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
+def test_fused_resblock_equals_unfused(voc_bf16, voc_bf16_unfused, oracle_voc_sd):
     """the fused kernels (rblock.hip: whole ResBlocks at C <= 64; vpair.hip: one ResBlock iteration at C = 128) and the
     per-convolution path have the same bf16
     rounding POINTS (conv inputs), fp32 accumulation and fp32 residual; their fp32 summation order differs (the fused
@@ -225,17 +253,8 @@ def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
     from oracle import hifigan_ref as href
     lens = [3, 50, 97]
     mels = [synth.random_mel(300 + i, n, f"fuse{i}") for i, n in enumerate(lens)]
-    old = os.environ.get("DTTS_VOC_FUSE")
-    try:
-        os.environ["DTTS_VOC_FUSE"] = "1"
-        a = voc_bf16.spec2wav_batch(mels)
-        os.environ["DTTS_VOC_FUSE"] = "0"
-        b = voc_bf16.spec2wav_batch(mels)
-    finally:
-        if old is None:
-            os.environ.pop("DTTS_VOC_FUSE", None)
-        else:
-            os.environ["DTTS_VOC_FUSE"] = old
+    a = voc_bf16.spec2wav_batch(mels)
+    b = voc_bf16_unfused.spec2wav_batch(mels)   # dtts_config.vocoder_unfused = 1: one kernel per convolution
     for x, y, n, m in zip(a, b, lens, mels):
         w = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), m).numpy()
         assert x.shape == y.shape == w.shape == (n * 256,)
@@ -247,7 +266,7 @@ def test_fused_resblock_equals_unfused(voc_bf16, oracle_voc_sd):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs 4, 5
-def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc_bf16, oracle_voc_sd):
+def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc, oracle_voc_sd):
     """BASELINE.json configs[3]: 1000-char input (T_w = 1002), teacher-forced 5 frames/char -> ~5k mel frames, B=1:
     attention over 1002 words, every conv tiled over 5k..1.28M time steps, mel and waveform vs the oracle"""
     from oracle import dict_tts_ref as ref
@@ -266,10 +285,10 @@ def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc_bf16, oracle_voc_
     assert (got["word_encoder_out"].cpu() - want["word_encoder_out"]).abs().max() <= 2e-4
     assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
     mel = want["mel_out"][0].numpy()
-    wav = voc_bf16.spec2wav(mel)
+    wav = voc.spec2wav(mel)
     wref = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel).numpy()
     assert wav.shape == wref.shape == (5012 * 256,)
-    assert abs(rms(wav) - rms(wref)) <= 1e-4 and rms(wav - wref) <= 0.02 * rms(wref)
+    wave_gate(wav, wref)
 
 
 def test_config5_dictionary_stress_mixed_lengths(acoustic, oracle_sd):
@@ -326,7 +345,8 @@ def test_resident_dictionary_ids_equal_collated_tensors(acoustic):
 
 
 @pytest.mark.gpu
-def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc_bf16, tmp_path):
+def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc, tmp_path):
+    voc_bf16 = voc
     """run_inference(pipeline=True) overlaps the vocoder of batch i with text->mel of batch i+1 on two streams; the
     files it writes must be byte-identical to the serial loop's (same kernels, same inputs, buffers never shared)"""
     from scipy.io import wavfile
@@ -354,7 +374,8 @@ def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc_bf16, tmp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm", [False, True])
-def test_device_int16_conversion_equals_reference_rule(voc_bf16, norm):
+def test_device_int16_conversion_equals_reference_rule(voc, norm):
+    voc_bf16 = voc
     """dtts_wav_to_int16 == utils/audio.py:11-16 per utterance over its own valid samples (wav / max|wav| if norm;
     * 32767 in fp32; truncating astype(int16)), bit for bit; samples past an utterance's end are 0"""
     from dict_tts_amd import infer

@@ -16,11 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=60)
 ap.add_argument("--T", type=int, default=740)
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--precision", default="bf16")
+ap.add_argument("--precision", default="f16")
 a = ap.parse_args()
 T_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config(),
-                      precision=abi.VOC_BF16 if a.precision == "bf16" else abi.VOC_BF16X3)
+                      precision=abi.VOC_PRECISIONS[a.precision])
 voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
 rng = np.random.default_rng(0)
 lens = np.clip(rng.normal(364, 110, a.B), 120, a.T).astype(np.int32)
