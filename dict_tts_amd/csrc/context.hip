@@ -1450,8 +1450,12 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     if (!mel2word) {
         LAUNCH(durations_launch(h->dur, ilens, starts, h->mel_lens, B, T_w, s));
         std::vector<int> tot(B);
+        int pm_host = 0;
         HIPCHK(hipMemcpyAsync(tot.data(), h->mel_lens, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&pm_host, pm_max, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));  // the one host sync of the path: T_mel sizes every later buffer
+        if (pm_host > DTTS_MAX_SENSES)   // the S2PA kernel keeps DTTS_MAX_SENSES sense slots; larger indices would silently get weight 0
+            return fail(h, DTTS_E_INVAL, "pinyin_map holds sense index %d; at most %d senses per word are supported", pm_host, DTTS_MAX_SENSES);
         for (int b = 0; b < B; ++b) T_raw = std::max(T_raw, tot[b]);
     } else {
         if (T_m2w <= 0) return fail(h, DTTS_E_INVAL, "mel2word given with T_m2w=%d", T_m2w);
@@ -1504,13 +1508,30 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
         if (tok_off[e + 1] < tok_off[e] || pin_off[e + 1] < pin_off[e])
             return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: offsets must be non-decreasing (entry %d)", e);
     std::vector<int> pmmax(n_entries, 0);
-    for (int e = 0; e < n_entries; ++e)
+    for (int e = 0; e < n_entries; ++e) {
         for (int p = pin_off[e]; p < pin_off[e + 1]; ++p) pmmax[e] = std::max(pmmax[e], (int)pinyin_map[p]);
+        float km = 0.f;
+        for (int l = tok_off[e]; l < tok_off[e + 1]; ++l) km = std::max(km, key_map[l]);
+        if (pmmax[e] > DTTS_MAX_SENSES || km > (float)DTTS_MAX_SENSES)
+            return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: entry %d has sense index %d; at most %d senses per word are supported",
+                        e, std::max(pmmax[e], (int)km), DTTS_MAX_SENSES);
+    }
+    if (h->t_entries) {   // a second upload replaces the table: release the previous one (nothing may still be using it)
+        HIPCHK(hipDeviceSynchronize());
+        void* old[] = {h->t_off, h->t_poff, h->t_pmmax, h->t_keys, h->t_values, h->t_key_map, h->t_pinyin, h->t_pinyin_map};
+        for (void* q : old) {
+            auto it = std::find(h->allocs.begin(), h->allocs.end(), q);
+            if (it == h->allocs.end()) continue;   // t_values aliases t_keys when the table was uploaded without values
+            (void)hipFree(q);
+            h->allocs.erase(it);
+        }
+        h->t_entries = 0;
+    }
     auto up = [&](const void* src, size_t bytes) -> void* {
         void* d = nullptr;
         if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        h->allocs.push_back(d);   // owned by the context from here on, also when the copy below fails
         if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        h->allocs.push_back(d);
         return d;
     };
     h->t_off = (int*)up(tok_off, sizeof(int) * (n_entries + 1));

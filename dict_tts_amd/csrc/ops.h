@@ -80,7 +80,7 @@ hipError_t dur_head_launch(const float* h, const float* w, const float* bias, co
 // prefix sum; total[b] = sum.                                            (model.py:78-81, tts_modules.py:215-251)
 hipError_t durations_launch(const float* dur, const int* ilens, int* starts, int* total, int B, int T, hipStream_t s);
 // mel2word[b, f] for f < T_mel: word index (1-based) or 0; columns >= T_raw repeat column T_raw-1 (model.py:98-100)
-hipError_t mel2word_fill_launch(const int* starts, const int* total, const int* ilens, int64_t* m2w, int B, int T_w,
+hipError_t mel2word_fill_launch(const int* starts, int* total, const int* ilens, int64_t* m2w, int B, int T_w,
                                 int T_raw, int T_mel, hipStream_t s);
 // teacher-forced: copy [B,T_in] i64 into [B,T_mel] with the same last-column padding; total[b] = #(m2w > 0)
 hipError_t mel2word_copy_launch(const int64_t* src, int64_t* dst, int* total, int B, int T_in, int T_mel, hipStream_t s);

@@ -817,7 +817,10 @@ hipError_t durations_launch(const float* dur, const int* ilens, int* starts, int
     return hipGetLastError();
 }
 
-__global__ void mel2word_fill_kernel(const int* starts, const int* total, int64_t* m2w, int T_w, int T_raw, int T_mel) {
+// total[b]: in = sum of the integer durations; out = number of frames with mel2word > 0 AFTER the padding to frames_multiple
+// (the padded columns repeat the last column, modules/dict_tts/model.py:98-100: an utterance that reaches T_raw keeps
+// them as valid frames, exactly as the reference's B = 1 inference vocodes all T_mel frames, tasks/tts/dict_tts.py:255)
+__global__ void mel2word_fill_kernel(const int* starts, int* total, int64_t* m2w, int T_w, int T_raw, int T_mel) {
     const int b = blockIdx.x;
     const int* st = starts + (long long)b * (T_w + 1);
     int64_t* row = m2w + (long long)b * T_mel;
@@ -830,8 +833,9 @@ __global__ void mel2word_fill_kernel(const int* starts, const int* total, int64_
     __syncthreads();
     const int64_t last = T_raw > 0 ? row[T_raw - 1] : 0;
     for (int f = T_raw + threadIdx.x; f < T_mel; f += blockDim.x) row[f] = last;
+    if (threadIdx.x == 0 && last > 0) total[b] = tot + (T_mel - T_raw);
 }
-hipError_t mel2word_fill_launch(const int* starts, const int* total, const int* ilens, int64_t* m2w, int B, int T_w,
+hipError_t mel2word_fill_launch(const int* starts, int* total, const int* ilens, int64_t* m2w, int B, int T_w,
                                 int T_raw, int T_mel, hipStream_t s) {
     (void)ilens;
     hipLaunchKernelGGL(mel2word_fill_kernel, dim3(B), dim3(256), 0, s, starts, total, m2w, T_w, T_raw, T_mel);

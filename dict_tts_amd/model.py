@@ -11,8 +11,8 @@ import numpy as np
 import torch
 
 from . import abi
+from . import hparams as hparams_mod
 from .hparams import fill_abi_config
-from .hparams import hparams as global_hparams
 
 # state-dict groups that exist in a Dict-TTS checkpoint but are never used by PortaSpeech_dict at inference
 # (SURVEY.md §8a "Parameter inventory"): accepted by load_state_dict, not uploaded
@@ -40,7 +40,12 @@ class PortaSpeech_dict(torch.nn.Module):
         super().__init__()
         if not torch.cuda.is_available():
             raise abi.DttsError("dict_tts_amd.model.PortaSpeech_dict needs a ROCm GPU: the HIP path has no CPU fallback")
-        hp = dict(global_hparams) if hparams is None else dict(hparams)
+        if hparams is None:   # the global hparams, looked up at call time (the INTEGRATION.md hook may rebind them late)
+            if not hparams_mod.hparams:
+                raise RuntimeError("PortaSpeech_dict(hparams=None) needs the global hparams: call dict_tts_amd.hparams.set_hparams(...) "
+                                   "or alias the reference's (INTEGRATION.md), or pass hparams={} for the Biaobei defaults")
+            hparams = hparams_mod.hparams
+        hp = dict(hparams)
         self.hparams = hp
         n_phone = len(dictionary) if dictionary is not None else None
         if ctx is None:

@@ -206,6 +206,22 @@ def biaobei_struct():
     return _STRUCT
 
 
+_FULL = None
+
+
+def zh_dict_struct():
+    """sense structure of ALL 7,030 zh-dict.json characters (oracle/make_biaobei_struct.py:write_full_dictionary):
+    {'n_entries', 'entries': word id (3 + rank) -> [[gloss_tokens, pinyin_initial_id, pinyin_final_id], ...]} — the table
+    of BASELINE.json configs[4] ("word_size=8000, full zh-dict.json entry set in HBM")"""
+    global _FULL
+    if _FULL is None:
+        with open(os.path.join(_DATA, "zh_dict_struct.json")) as f:
+            d = json.load(f)
+        d["entries"] = {int(k): v for k, v in d["entries"].items()}
+        _FULL = d
+    return _FULL
+
+
 BOS_ID, EOS_ID = 1203, 1204  # any ids >= 3 outside the char range; '<BOS>'/'<EOS>' are ordinary vocabulary words
 
 

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import abi
-from .hparams import HIFIGAN_DEFAULTS, fill_abi_config, hparams, load_config_chain
+from . import hparams as hparams_mod
+from .hparams import HIFIGAN_DEFAULTS, fill_abi_config, load_config_chain
 
 VOCODERS = {}
 
@@ -62,7 +63,8 @@ class HifiGAN:
 
     def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False):
         if state_dict is None:
-            config, state_dict = find_vocoder_checkpoint(hparams["vocoder_ckpt"])
+            config, state_dict = find_vocoder_checkpoint(hparams_mod.hparams["vocoder_ckpt"])   # looked up at call time: the
+            # INTEGRATION.md hook may rebind dict_tts_amd.hparams.hparams after this module was imported
         self.config = {**HIFIGAN_DEFAULTS, **(config or {})}
         if not torch.cuda.is_available():
             raise abi.DttsError("dict_tts_amd.vocoder.HifiGAN needs a ROCm GPU: the HIP path has no CPU fallback")

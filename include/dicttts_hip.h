@@ -37,6 +37,12 @@ typedef void* dtts_stream; /* hipStream_t */
 #define DTTS_F32 0
 #define DTTS_I64 1
 
+/* Largest sense index (key_map / pinyin_map value) a word may carry: the S2PA kernel keeps 16 sense slots, index 0 = "no
+ * sense".  zh-dict.json holds at most 6 pronunciations per character.  Larger indices are rejected (DTTS_E_INVAL) by dtts_dict_table_upload and, on the
+ * tensor API, at the T_mel synchronisation of dtts_text2mel_encode; with teacher-forced mel2word (no synchronisation) they
+ * are not checked and get weight 0. */
+#define DTTS_MAX_SENSES 15
+
 /* vocoder arithmetic (fp32 accumulation and an fp32 residual stream in every mode).
  *   DTTS_VOC_F16 (default): the fused kernels with fp16 MFMA operands in the ResBlocks and bf16 hi/lo split operands (three
  *     products) in the six serial convolutions (conv_pre, upsamplers, conv_post: 3 % of the FLOPs but 87 % of the 16-bit
@@ -191,7 +197,8 @@ int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens_dev, con
 #define DTTS_OUT_WORD_ENCODER_OUT 5 /* [B,T_w,hidden] f32                           */
 #define DTTS_OUT_X_MASK 6           /* [B,T_mel,1] f32    ret['x_mask']             */
 #define DTTS_OUT_CONTEXT 7          /* [B,T_w,hidden] f32 S2PA context              */
-#define DTTS_OUT_MEL_LENS 8         /* [B] i32 valid (unpadded) frames per utterance */
+#define DTTS_OUT_MEL_LENS 8         /* [B] i32 frames with mel2word > 0 AFTER the padding to frames_multiple (the frames the
+                                      reference's B = 1 inference vocodes: an utterance that reaches T_mel keeps its pad frames) */
 int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stream);
 
 /*

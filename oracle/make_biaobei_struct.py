@@ -51,6 +51,40 @@ def split_pinyin(p):
     return ini, fin
 
 
+def write_full_dictionary(zh):
+    """BASELINE.json configs[4] ("word_size=8000, full zh-dict.json entry set in HBM"): the sense structure of ALL
+    zh-dict.json characters, same per-sense rule as above.  Word id = 3 + rank of the character in the sorted key set
+    (ids 3 .. 3 + n - 1 < word_size 8000); pinyin-token ids in first-seen order after '<UNK>', folded into 1..184
+    (value_embedding_size = 185).  -> dict_tts_amd/data/zh_dict_struct.json (integers only)."""
+    chars = sorted(zh)
+    pinyin_tokens = ["<UNK>"]
+
+    def pid(tok):
+        if tok not in pinyin_tokens:
+            pinyin_tokens.append(tok)
+        i = pinyin_tokens.index(tok)
+        return i if i <= 184 else 1 + (i % 184)
+
+    entries = {}
+    for r, c in enumerate(chars):
+        senses = []
+        for pinyin, glosses in zh[c].items():
+            gloss = "".join(glosses).replace("～", c)
+            gloss = re.sub(r"[^一-鿿，。！？；：、,.!?;:]", "", gloss)
+            ini, fin = split_pinyin(pinyin)
+            senses.append([min(len(gloss), 30) + 2, pid(ini), pid(fin)])
+        entries[3 + r] = senses
+    out = {"source": "zh-dict.json, all characters; integers only", "n_entries": len(chars),
+           "entries": {str(k): v for k, v in entries.items()}}
+    path = os.path.join(os.path.dirname(OUT), "zh_dict_struct.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    ns = [len(v) for v in entries.values()]
+    print("full dictionary:", len(chars), "entries, senses max", max(ns), "heteronyms", sum(n > 1 for n in ns),
+          "gloss tokens", sum(s[0] for v in entries.values() for s in v), "pinyin tokens", len(pinyin_tokens), "bytes",
+          os.path.getsize(path))
+
+
 def main():
     zh = json.load(open(os.path.join(REF, "data", "zh-dict.json"), encoding="utf-8"))
     rows = list(csv.DictReader(open(os.path.join(REF, "scripts", "pron_label", "label_set0.csv"), encoding="utf-8")))
@@ -96,6 +130,7 @@ def main():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(out, f, separators=(",", ":"))
+    write_full_dictionary(zh)
     lens = [len(s) for s in out["sentences"]]
     print("sentences", len(lens), "chars/sent min/mean/max", min(lens), sum(lens) / len(lens), max(lens),
           "distinct chars", len(chars), "pinyin tokens", n_tok, "bytes", os.path.getsize(OUT))

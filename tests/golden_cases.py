@@ -122,3 +122,46 @@ def g8_inputs(which):
 
 G8_CASES = {"dec": dict(layers=4, kernel_size=9, use_pos_embed=True, use_last_norm=True),
             "enc": dict(layers=2, kernel_size=5, use_pos_embed=False, use_last_norm=True)}
+
+
+def g9_wavs():
+    """G9 (output side, utils/audio.py:11-16): three float32 waveforms in (-1, 1) like the vocoder's tanh output, ragged
+    lengths (frames 3 / 7 / 1, hop 256), values scaled so that w * 32767 has fractions on both sides of .5, one exact 0
+    and one sample pair at +-0.999969 (the int16 edge)."""
+    lens = [3, 7, 1]
+    out = []
+    for i, n in enumerate(lens):
+        w = np.tanh(synth.randn(SEED, f"g9.wav{i}", (n * 256,), 0.6)).astype(np.float32)
+        w[0] = 0.0
+        w[1], w[2] = np.float32(0.999969), np.float32(-0.999969)
+        out.append(w)
+    return lens, out
+
+
+G10_WORDS = None
+
+
+def g10_entries():
+    """G10 (dict_embed fixture, utils/indexed_datasets.py:41-54 + binarizer_zh.py:250-259,301-309): four ``dict_embed`` items in
+    the reference's item layout — an absent character (zero entry), a one-sense word, a two-sense heteronym and a
+    three-sense one (gloss lengths cut to <= 8 tokens to keep the fixture small) — plus the pinyin encoder list."""
+    st = synth.biaobei_struct()
+    by_senses = {}
+    for w, senses in sorted(st["entries"].items()):
+        n = 0 if senses[0][2] < 0 else len(senses)
+        by_senses.setdefault(n, w)
+    words = [2, by_senses[1], by_senses[2], by_senses[3]]   # 2 = '<UNK>': what the binarizer writes for a word outside zh-dict.json
+    pinyin_encoder = ["<UNK>"] + [f"py{i}" for i in range(1, 185)]
+    items = []
+    for w in words:
+        senses = st["entries"].get(w, [[3, 0, -1]])
+        if senses[0][2] < 0:
+            items.append({"tokens_gloss": ["O"], "key": np.zeros((3, 768), np.float32), "key_map": [0, 1, 0],
+                          "pinyin": ["<UNK>"], "pinyin_map": [1]})
+            continue
+        short = {w: [[min(n, 8), a, b] for n, a, b in senses]}
+        emb, km, py, pm = synth.dict_entry(w, SEED, short)
+        items.append({"tokens_gloss": ["<sos>"] + ["t"] * (emb.shape[0] - 2) + ["<eos>"], "key": emb,
+                      "key_map": [int(v) for v in km], "pinyin": [pinyin_encoder[int(i)] for i in py],
+                      "pinyin_map": [int(v) for v in pm]})
+    return words, items, pinyin_encoder

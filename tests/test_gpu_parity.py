@@ -397,6 +397,173 @@ def test_device_int16_conversion_equals_reference_rule(voc, norm):
         assert got[0, :6].tolist() == [0, 16383, -16383, 32766, -32767, 32767]
 
 
+def test_device_int16_conversion_vs_reference_save_wav_golden(voc, golden_dir):
+    """G9: dtts_wav_to_int16 on a ragged batch == the samples the REFERENCE's save_wav wrote (utils/audio.py:11-16,
+    oracle/make_golden_io.py), norm off and on, and == the oracle restatement; samples past an utterance's end are 0"""
+    from oracle import audio_ref
+    g = np.load(os.path.join(golden_dir, "g9_save_wav.npz"))
+    lens, wavs = gc.g9_wavs()
+    hop = voc.hop
+    assert hop == 256
+    batch = np.zeros((len(wavs), max(lens) * hop), np.float32)
+    for i, w in enumerate(wavs):
+        batch[i, :w.shape[0]] = w
+    batch[0, lens[0] * hop:] = 0.97                      # junk past the end of utterance 0: must not enter its peak
+    for norm in (False, True):
+        got = voc.to_int16(T(batch).cuda(), T(np.array(lens, np.int32)).cuda(), norm=norm).cpu().numpy()
+        for i, n in enumerate(lens):
+            want = g[f"u{i}.norm{int(norm)}"]
+            assert np.array_equal(got[i, :n * hop], want), (i, norm)
+            assert np.array_equal(audio_ref.save_wav_pcm(wavs[i], norm), want)
+            assert not got[i, n * hop:].any()
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[1] at full size
+def test_config2_batch60_full_size_vs_oracle(acoustic, oracle_sd, voc, oracle_voc_sd):
+    """BASELINE.json configs[1] at its real size: the first 60 Biaobei sentences as ONE batch (T_w = 27, L_k = 148).
+    (1) predicted durations: integer mel2word exact, pinyin strings identical, mel <= 1e-3 on every frame (the decoder
+        runs unmasked over the padded batch, SURVEY 0.3, so padding leakage at B = 60 is part of the comparison);
+    (2) teacher-forced 22 frames / char (T_mel = 740, the bench shape): mel <= 1e-3 on all 60 x 740 frames, and the
+        waveform gates RMS(gpu - ref), |RMS(gpu) - RMS(ref)| <= 1e-4 end to end (GPU mel -> GPU vocoder against oracle mel ->
+        oracle vocoder) on the shortest, a middle and the longest utterance."""
+    from dict_tts_amd.model import decode_pinyin_ids
+    from oracle import dict_tts_ref as ref
+    from oracle import hifigan_ref as href
+    st = synth.biaobei_struct()
+    batch = synth.make_batch(st["sentences"][:60], gc.SEED)
+    B, T_w = batch["word_tokens"].shape
+    assert (B, T_w, batch["keys"].shape[2]) == (60, 27, 148)
+    b = {k: T(v) for k, v in batch.items()}
+    dm = (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"])
+    # (1) predicted durations
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], dm, b["pron_modified"], z_p=lambda B_, T4: T(synth.noise(61, B_, T4)))
+    T_mel = want["mel_out"].shape[1]
+    got = _run(acoustic, batch, z=T(synth.noise(61, B, T_mel // 4)))
+    assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-4
+    # integer durations: exact wherever the reference's own round() is numerically decided.  Among the 1,157 words of this
+    # batch one sits ON a rounding boundary (utterance 49, word 14: exp(dur) - 1 = 7.499998 on the CPU, 7.500009 here, log
+    # durations 8e-6 apart): fp32 implementations cannot agree there (neither do two CPU thread counts), so such numerical
+    # ties (|frac - .5| < 5e-5 in the oracle) are listed and excluded, and everything else must be identical.
+    v = want["dur"].exp() - 1
+    tie = ((v - v.floor() - 0.5).abs() < 5e-5) & (b["word_tokens"] > 0)
+    gi = (got["dur"].cpu().exp() - 1).round().clamp(min=0)
+    wi = v.round().clamp(min=0)
+    assert int(tie.sum()) <= 2 and torch.equal(gi[~tie], wi[~tie]), (int(tie.sum()), int((gi != wi).sum()))
+    if not torch.equal(got["mel2word"].cpu(), want["mel2word"]):   # a tie went the other way: compare the rest on the SAME durations
+        assert bool(((gi != wi) & ~tie).sum() == 0)
+        want = ref.forward_infer(oracle_sd, b["word_tokens"], dm, b["pron_modified"], mel2word=got["mel2word"].cpu(),
+                                 z_p=lambda B_, T4: T(synth.noise(61, B_, T4)))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"]) and got["mel_out"].shape == want["mel_out"].shape
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    for u in range(B):
+        assert decode_pinyin_ids(got["pron_attn"][u], batch["pinyin"][u]) == ref.decode_pinyin(want["pron_attn"][u], b["pinyin"][u])
+    # (2) the bench shape
+    m2w = synth.teacher_mel2word(batch["word_tokens"])
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], dm, b["pron_modified"], mel2word=T(m2w),
+                             z_p=lambda B_, T4: T(synth.noise(62, B_, T4)))
+    T_mel = want["mel_out"].shape[1]
+    assert T_mel % 4 == 0 and T_mel >= 500
+    got = _run(acoustic, batch, z=T(synth.noise(62, B, T_mel // 4)), mel2word=T(m2w))
+    assert got["mel_out"].shape == want["mel_out"].shape
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    lens = got["mel_lens"].cpu().numpy()
+    assert np.array_equal(lens, (want["mel2word"] > 0).sum(1).numpy())
+    wav = voc.forward_batch(got["mel_out"], got["mel_lens"]).cpu().numpy()
+    order = np.argsort(lens)
+    for u in (int(order[0]), int(order[len(order) // 2]), int(order[-1])):
+        n = int(lens[u])
+        wref = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), want["mel_out"][u, :n].numpy()).numpy()
+        wave_gate(wav[u, :n * voc.hop], wref)
+        assert not wav[u, n * voc.hop:].any()
+
+
+def test_b1_waveform_covers_the_padded_frames(acoustic, oracle_sd, voc, oracle_voc_sd, tmp_path):
+    """the reference's inference is B = 1 and vocodes ALL T_mel frames of mel_out, including the <= 3 frames added by the
+    padding to frames_multiple (they repeat the last word and are valid frames; tasks/tts/dict_tts.py:255): mel_lens
+    counts them, run_inference writes T_mel * hop samples and the tail equals spec2wav(mel_out) of the oracle"""
+    from scipy.io import wavfile
+    from dict_tts_amd import infer
+    from oracle import audio_ref
+    from oracle import dict_tts_ref as ref
+    from oracle import hifigan_ref as href
+    st = synth.biaobei_struct()
+    hit = False
+    for k in range(6):
+        batch = synth.make_batch([st["sentences"][k]], gc.SEED)
+        b = {key: T(v) for key, v in batch.items()}
+        want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                                 b["pron_modified"], z_p=lambda B_, T4: T(synth.noise(70 + k, B_, T4)))
+        T_mel = want["mel_out"].shape[1]
+        raw = int((want["dur"].exp() - 1).round().clamp(min=0).sum())
+        got = _run(acoustic, batch, z=T(synth.noise(70 + k, 1, T_mel // 4)))
+        assert int(got["mel_lens"][0]) == T_mel == int((want["mel2word"] > 0).sum())
+        if raw % 4 == 0:
+            continue
+        hit = True                                        # this utterance really has pad frames
+        wref = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), want["mel_out"][0].numpy()).numpy()
+        bt = dict(b)
+        bt["item_name"], bt["text"] = ["u"], ["t"]
+        bt["z_p"] = T(synth.noise(70 + k, 1, T_mel // 4))
+        rows = infer.run_inference(acoustic, voc, [bt], str(tmp_path / f"b1_{k}"), [f"p{i}" for i in range(185)], pipeline=False)
+        pcm = wavfile.read(os.path.join(tmp_path / f"b1_{k}", "wavs", rows[0]["wav_fn_pred"] + ".wav"))[1]
+        assert pcm.shape == (T_mel * voc.hop,)
+        wpcm = audio_ref.save_wav_pcm(wref)
+        tail = slice((raw - 2) * voc.hop, T_mel * voc.hop)
+        d = pcm[tail].astype(np.float64) - wpcm[tail].astype(np.float64)
+        assert rms(d) <= 1e-4 * 32767 + 0.5 and np.abs(d).max() <= 40, (rms(d), np.abs(d).max())   # the waveform gate in int16 LSBs (+ truncation)
+        break
+    assert hit, "none of the six sentences needed padding to frames_multiple"
+
+
+def test_config5_full_dictionary_resident_table_vs_oracle(acoustic, oracle_sd):
+    """BASELINE.json configs[4] with the FULL dictionary: all 7,030 zh-dict.json entries (211,072 gloss rows, 618 MiB)
+    resident in HBM, uploaded once; one GPU's share of the batch (B = 32 mixed-length utterances of 6..60 characters
+    drawn from the whole dictionary, heteronyms over-sampled x5, word ids up to 7,999) runs from ids only and is
+    compared with the ORACLE on the tensors the reference's collater would build from the same entries (SURVEY 8f-1:
+    the id path against the reference arithmetic, not against the HIP tensor path)."""
+    from dict_tts_amd.model import decode_pinyin_ids
+    from oracle import dict_tts_ref as ref
+    full = synth.zh_dict_struct()
+    ent = full["entries"]
+    assert full["n_entries"] == len(ent) == 7030 and max(ent) == 7032
+    table = synth.dict_table(gc.SEED, ent)
+    assert table["keys"].shape == (211072, 768)
+    acoustic.upload_dict_table(table)
+    rng = np.random.default_rng(55)
+    ids = np.array(sorted(ent))
+    wts = np.array([5.0 if len(ent[i]) > 1 else 1.0 for i in ids])
+    wts /= wts.sum()
+    sents = [rng.choice(ids, size=int(rng.integers(6, 61)), p=wts).tolist() for _ in range(32)]
+    sents[0][0], sents[1][-1] = int(ids[0]), int(ids[-1])            # first and last table rows
+    ib = synth.make_id_batch(sents, table, pron_every=3)
+    tb = synth.make_batch(sents, gc.SEED, ent, pron_every=3)
+    for k in ("word_tokens",):
+        ib[k][ib[k] == synth.BOS_ID] = 7999
+        tb[k][tb[k] == synth.BOS_ID] = 7999
+    assert np.array_equal(ib["word_tokens"], tb["word_tokens"]) and np.array_equal(ib["pron_modified"], tb["pron_modified"])
+    assert (ib["L_k"], ib["P"]) == (tb["keys"].shape[2], tb["pinyin"].shape[2])
+    b = {k: T(v) for k, v in tb.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], z_p=lambda B_, T4: T(synth.noise(33, B_, T4)))
+    T_mel = want["mel_out"].shape[1]
+    got = acoustic.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"],
+                               z_p=T(synth.noise(33, 32, T_mel // 4)))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"])
+    assert (got["pron_attn"].cpu() - want["pron_attn"]).abs().max() <= 1e-5
+    assert (got["dict_attn"].cpu() - want["dict_attn"]).abs().max() <= 1e-5
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    for u in range(32):
+        assert decode_pinyin_ids(got["pron_attn"][u], tb["pinyin"][u]) == ref.decode_pinyin(want["pron_attn"][u], b["pinyin"][u])
+    # a second upload replaces the table (the previous one is released) and the Biaobei table still works afterwards
+    acoustic.upload_dict_table(synth.dict_table(gc.SEED))
+    # sense indices beyond DTTS_MAX_SENSES are rejected, not silently zero-weighted
+    bad = synth.dict_table(gc.SEED)
+    bad["pinyin_map"] = bad["pinyin_map"].copy()
+    bad["pinyin_map"][0] = 16
+    with pytest.raises(abi.DttsError, match="at most 15 senses"):
+        acoustic.upload_dict_table(bad)
+
+
 @pytest.mark.gpu
 def test_s2pa_long_words_vs_oracle_and_repeatable(acoustic, oracle_sd):
     """words with many live gloss rows (64 / 65 / 128 / 129 / 158 of 160, NON-zero glosses so that a missed row would
