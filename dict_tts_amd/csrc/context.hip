@@ -1628,8 +1628,7 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
 }
 
 int dtts_text2mel_decode(dtts_handle h, const float* z_p, float* mel_out, dtts_stream stream) {
-    if (h && !z_p) return fail(h, DTTS_E_INVAL, "dtts_text2mel_decode: null argument");
-    return decode_impl(h, z_p, 0, mel_out, 0, stream);
+    return decode_impl(h, z_p, 0, mel_out, 0, stream);   // z_p == NULL: the prior sample is drawn on the device
 }
 
 // ---- the single-call forms and names of SURVEY.md 8(b)

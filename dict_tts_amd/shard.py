@@ -1,15 +1,18 @@
 """Utterance-level data parallelism: one process per GPU, no collective on the data path.
 
 Mirrors the reference's rule for distributing test batches over ranks (tasks/tts/tts_base.py:114-127,148-151):
-batches are built for world*max_sentences utterances and rank r keeps elements ``r::world``.  The optional
-all-gather of mels (BASELINE.json north_star, "whole-node throughput runs") is the only collective; it works on
-fixed-capacity padded buffers plus a length vector, so it is one call regardless of the ragged T_mel per rank.
+batches are built for world*max_sentences utterances and rank r keeps elements ``r::world``.  The reference DROPS a
+batch whose size is not divisible by the number of replicas (tts_base.py:150); here the tail chunk is kept (every test
+sentence is synthesised), so ranks may hold different batch sizes, or none at all, in the last step — which is why the
+optional all-gather of mels (BASELINE.json north_star, "whole-node throughput runs") first exchanges (B, T_mel) per rank
+and then gathers buffers padded to the maxima; a rank without a batch still enters both collectives.
 """
 import torch
 
 
 def shard_indices(n_items, rank, world, max_sentences=60):
-    """-> list of batches (lists of item indices) this rank processes; union over ranks = range(n_items), disjoint"""
+    """-> list of batches (lists of item indices) this rank processes; union over ranks = range(n_items), disjoint.
+    A rank gets NO batch for a chunk it has no element of (n_items=2, world=4): use ``n_steps`` for the common step count."""
     batches = []
     step = world * max_sentences
     for start in range(0, n_items, step):
@@ -20,18 +23,38 @@ def shard_indices(n_items, rank, world, max_sentences=60):
     return batches
 
 
-def gather_mels(mel, lens, cap, dist, group=None, out=None):
-    """mel [B,T,80], lens [B] (any device the backend supports) -> (mel_all [world*B,cap,80], lens_all [world*B]).
-    Rank-major order; utterance i of rank r lands at r*B + i.  T may differ per rank (T <= cap)."""
-    B, T, C = mel.shape
-    assert T <= cap, (T, cap)
+def n_steps(n_items, world, max_sentences=60):
+    """number of chunks = steps every rank must take part in (collectives included), whether or not it holds a batch"""
+    step = world * max_sentences
+    return (n_items + step - 1) // step
+
+
+def gather_mels(mel, lens, dist, group=None, n_mel=80, comm_device=None):
+    """All-gather of one step's mels with ragged B and T_mel per rank.
+    mel [B,T,n_mel] f32 / lens [B] i32, or (None, None) on a rank that has no batch in this step.
+    -> (mel_all [world, B_max, T_max, n_mel], lens_all [world, B_max] (0 = no utterance), meta [world, 2] = (B, T) per rank),
+    or (None, None, meta) when no rank has a batch.  Two collectives: the 2-int shape exchange, then the padded gather.
+    comm_device: where the collective runs (default: the tensors' device; pass 'cpu' for a gloo group fed CUDA tensors)."""
     world = dist.get_world_size(group)
-    pad = mel.new_zeros(B, cap, C)
-    pad[:, :T] = mel
-    mel_all = out if out is not None else mel.new_empty(world * B, cap, C)
-    lens_all = lens.new_empty(world * B)
+    src_dev = mel.device if mel is not None else torch.device("cpu")
+    dev = torch.device(comm_device) if comm_device is not None else src_dev
+    B, T = (int(mel.shape[0]), int(mel.shape[1])) if mel is not None else (0, 0)
+    meta = torch.tensor([B, T], dtype=torch.int32, device=dev)
+    meta_all = torch.empty(world * 2, dtype=torch.int32, device=dev)   # outputs are the dim-0 concatenation (gloo insists on it)
+    dist.all_gather_into_tensor(meta_all, meta, group=group)
+    meta_h = meta_all.view(world, 2).cpu()
+    Bm, Tm = int(meta_h[:, 0].max()), int(meta_h[:, 1].max())
+    if Bm == 0:
+        return None, None, meta_h
+    pad = torch.zeros(Bm, Tm, n_mel, dtype=torch.float32, device=dev)
+    lp = torch.zeros(Bm, dtype=torch.int32, device=dev)
+    if mel is not None:
+        pad[:B, :T] = mel.to(dev)
+        lp[:B] = lens.to(device=dev, dtype=torch.int32)
+    mel_all = torch.empty(world * Bm, Tm, n_mel, dtype=torch.float32, device=dev)
+    lens_all = torch.empty(world * Bm, dtype=torch.int32, device=dev)
     w1 = dist.all_gather_into_tensor(mel_all, pad, group=group, async_op=True)
-    w2 = dist.all_gather_into_tensor(lens_all, lens.contiguous(), group=group, async_op=True)
+    w2 = dist.all_gather_into_tensor(lens_all, lp, group=group, async_op=True)
     w1.wait()
     w2.wait()
-    return mel_all, lens_all
+    return mel_all.view(world, Bm, Tm, n_mel), lens_all.view(world, Bm), meta_h

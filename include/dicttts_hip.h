@@ -161,7 +161,8 @@ int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, cons
 /*
  * Acoustic model, phase 2 — replaces the gather-expand and run_decoder (model.py:105-121,
  * fvae_semantics.py:109-115): z_p [B,latent,T_mel/4] f32 is the prior sample (the reference draws it from the
- * CPU RNG; here it is an explicit input).  mel_out [B,T_mel,80] f32.
+ * CPU RNG; here it is an explicit input for parity runs) or NULL: N(0,1) drawn on the device (counter-based, a new stream
+ * per call).  mel_out [B,T_mel,80] f32.
  */
 int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev, dtts_stream stream);
 

@@ -763,3 +763,44 @@ def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
         assert torch.equal(got["mel2word"].cpu(), want["mel2word"]), k
         assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-5
         assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 control flow on one GPU
+def test_bench_two_ranks_on_one_device_testset_sharding():
+    """bench.py --gpus 2 --workload testset (BASELINE configs[2]: all 200 test sentences, utterance i -> rank i mod N in
+    batches <= 60, tasks/tts/tts_base.py:148-151) launched with torch.distributed.run as the driver does, both ranks mapped to
+    cuda:0 (DTTS_BENCH_ONE_DEVICE=1, gloo): rendezvous, shard_indices, the (B, T_mel) exchange + padded mel all-gather, barriers,
+    max-over-ranks timing and the frame all-reduce all execute.  The two ranks together must produce the frames of the 1-rank
+    pass over the same 200 sentences to within 0.5 %: an utterance's durations depend slightly on its batch (the collater puts
+    key_map = pinyin_map = 1 on the LAST row of the padded batch, dataset_utils.py:288-300, which only the longest utterance's
+    EOS occupies, and the longest utterance keeps the <= 3 frames_multiple pad frames), so the totals are close, not equal."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "1", "--workload", "testset", "--no-cpu-baseline", "--no-side"]
+
+    def run(cmd, env):
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DTTS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["config"]["batches_per_step"] == 4 and two["config"]["batches_per_step"] == 2      # 200 / 60 and 200 / 120 chunks
+    f1 = one["value"] * one["ms_per_step"] * 1e-3
+    f2 = two["value"] * two["ms_per_step"] * 1e-3
+    assert abs(f1 - f2) <= 0.005 * f1 and f1 > 200 * 100, (f1, f2)
+    g = two["mel_allgather"]
+    assert g["enabled"] and g["calls"] == 2 * 2 and g["disabled_reason"] is None          # (warm-up + timed) x 2 chunks
+    meta = g["last_meta"]                                   # last chunk: sentences 120..199 -> 40 per rank
+    assert len(meta) == 2 and meta[0][0] == meta[1][0] == 40 and min(meta[0][1], meta[1][1]) > 100
+    assert "+allgather(mel)" in two["config"]["parallelism"] and one["mel_allgather"]["enabled"] is False

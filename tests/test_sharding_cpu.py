@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dict_tts_amd.shard import gather_mels, shard_indices
+from dict_tts_amd.shard import gather_mels, n_steps, shard_indices
 
 
 def test_shard_indices_partition():
@@ -21,23 +21,48 @@ def test_shard_indices_partition():
         assert sorted(seen) == list(range(n))
     # the reference's rule: element i of a world*max_sentences chunk goes to rank i % world
     assert shard_indices(10, 1, 2, 3) == [[1, 3, 5], [7, 9]]
+    # BASELINE configs[2]: the 200-sentence test set over 8 GPUs = one chunk, utterance i -> rank i mod 8, 25 each
+    assert all(shard_indices(200, r, 8, 60) == [list(range(r, 200, 8))] for r in range(8)) and n_steps(200, 8, 60) == 1
+    # the tail chunk may leave ranks without a batch: the step count is common, the batch lists are not
+    assert n_steps(2, 4, 1) == 1 and [len(shard_indices(2, r, 4, 1)) for r in range(4)] == [1, 1, 0, 0]
+    assert n_steps(200, 1, 60) == 4 and [len(b) for b in shard_indices(200, 0, 1, 60)] == [60, 60, 60, 20]
 
 
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, cap = 3, 12
-    T = 8 if rank == 0 else 5            # ragged T_mel per rank
-    mel = torch.arange(B * T * 80, dtype=torch.float32).reshape(B, T, 80) + 1000 * rank
-    lens = torch.tensor([T, T - 1, T - 2], dtype=torch.int32)
-    mel_all, lens_all = gather_mels(mel, lens, cap, dist)
-    ok = mel_all.shape == (world * B, cap, 80)
-    for r in range(world):
-        Tr = 8 if r == 0 else 5
-        want = torch.arange(B * Tr * 80, dtype=torch.float32).reshape(B, Tr, 80) + 1000 * r
-        ok = ok and torch.equal(mel_all[r * B:(r + 1) * B, :Tr], want) and float(mel_all[r * B:(r + 1) * B, Tr:].abs().max()) == 0
-        ok = ok and lens_all[r * B:(r + 1) * B].tolist() == [Tr, Tr - 1, Tr - 2]
+    ok = True
+    # step 0: ragged B and T_mel per rank (rank 0: 3 x 8, rank 1: 2 x 5); step 1: rank 1 has NO batch (the tail chunk of
+    # shard_indices) but still enters the collectives; step 2: nobody has one
+    shapes = {0: {0: (3, 8), 1: (2, 5)}, 1: {0: (1, 4), 1: None}, 2: {0: None, 1: None}}
+
+    def mk(r, step):
+        bt = shapes[step][r]
+        if bt is None:
+            return None, None
+        B, T = bt
+        mel = torch.arange(B * T * 80, dtype=torch.float32).reshape(B, T, 80) + 1000 * r + 7 * step
+        return mel, torch.arange(T, T - B, -1, dtype=torch.int32)
+
+    for step in range(3):
+        mel, lens = mk(rank, step)
+        mel_all, lens_all, meta = gather_mels(mel, lens, dist)
+        want_meta = [list(shapes[step][r] or (0, 0)) for r in range(world)]
+        ok = ok and meta.tolist() == want_meta
+        if step == 2:
+            ok = ok and mel_all is None and lens_all is None
+            continue
+        Bm, Tm = max(m[0] for m in want_meta), max(m[1] for m in want_meta)
+        ok = ok and tuple(mel_all.shape) == (world, Bm, Tm, 80) and tuple(lens_all.shape) == (world, Bm)
+        for r in range(world):
+            wm, wl = mk(r, step)
+            if wm is None:
+                ok = ok and float(mel_all[r].abs().max()) == 0 and lens_all[r].tolist() == [0] * Bm
+                continue
+            B, T = wm.shape[:2]
+            ok = ok and torch.equal(mel_all[r, :B, :T], wm) and float(mel_all[r, B:].abs().sum()) == 0
+            ok = ok and float(mel_all[r, :, T:].abs().sum()) == 0 and lens_all[r, :B].tolist() == wl.tolist()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
