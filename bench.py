@@ -384,7 +384,11 @@ def main():
             side[name] = {"mel_frames_per_s": fr / dt, "ms_per_step": dt / (n * steps_per_pass) * 1e3, "steps": n, "what": what}
         # per-stage rates and the rooflines SURVEY.md 8(d) names for the other two stages, one stream, 3 repetitions
         m.ctx.timer_enable(abi.TIMER_S2PA)
+        for tm in (abi.TIMER_STAGE_ENCODER, abi.TIMER_STAGE_DICT_ENCODER, abi.TIMER_STAGE_FVAE):
+            m.ctx.timer_enable(tm)
+        voc.ctx.timer_enable(abi.TIMER_STAGE_HIFIGAN)
         m.ctx.timer_reset()
+        voc.ctx.timer_reset()
         hb = next(b for b in batches if b is not None)
         d = {k: hb[k].to(dev) for k in ("word_tokens", "entry_ids", "pron_modified")}
         ms_enc = ms_dec = ms_voc = 0.0
@@ -407,9 +411,13 @@ def main():
             ms_dec += ev[1].elapsed_time(ev[2]) / 3
             ms_voc += ev[2].elapsed_time(ev[3]) / 3
         s2pa_ms, s2pa_n = m.ctx.timer_read(abi.TIMER_S2PA)
+        per_call = lambda ctx, which: (lambda ms, n: ms / max(n, 1))(*ctx.timer_read(which))
+        ref_names = {"encoder": per_call(m.ctx, abi.TIMER_STAGE_ENCODER), "dict_encoder": per_call(m.ctx, abi.TIMER_STAGE_DICT_ENCODER),
+                     "fvae": per_call(m.ctx, abi.TIMER_STAGE_FVAE), "hifigan": per_call(voc.ctx, abi.TIMER_STAGE_HIFIGAN)}
         fr = int(lens_i.sum().item())
         dec_tf = FLOP_PER_FRAME_DECODER * hb["B"] * T_m / (ms_dec * 1e-3) / 1e12
         stages = {"isolated": True, "batch": "first batch of this rank", "mel_frames_per_batch": fr,
+                  "reference_profile_infer_timers_ms": ref_names,   # utils.Timer names of modules/dict_tts/model.py:50,57,86, vocoders/hifigan.py:59
                   "text2mel": {"ms": ms_enc + ms_dec, "encode_ms": ms_enc, "decode_ms": ms_dec,
                                "mel_frames_per_s": fr / ((ms_enc + ms_dec) * 1e-3)},
                   "vocoder": {"ms": ms_voc, "mel_frames_per_s": fr / (ms_voc * 1e-3)},

@@ -17,6 +17,7 @@ VOC_PRECISIONS = {"f16": VOC_F16, "bf16": VOC_BF16, "bf16x3": VOC_BF16X3}
 PART_ACOUSTIC, PART_VOCODER, PART_FFT = 1, 2, 4
 OUT_PRON_ATTN, OUT_DUR, OUT_MEL2WORD, OUT_DICT_ATTN, OUT_WORD_ENCODER_OUT, OUT_X_MASK, OUT_CONTEXT, OUT_MEL_LENS = range(1, 9)
 TIMER_VOC_CONV, TIMER_S2PA = 1, 2
+TIMER_STAGE_ENCODER, TIMER_STAGE_DICT_ENCODER, TIMER_STAGE_FVAE, TIMER_STAGE_HIFIGAN = 3, 4, 5, 6   # the reference's profile_infer names
 
 EXPORTS = ["dtts_default_config", "dtts_config_sizeof", "dtts_create", "dtts_destroy", "dtts_last_error", "dtts_load_weight",
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
@@ -36,7 +37,7 @@ class DttsConfig(C.Structure):
         ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("n_resblock_kernels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
         ("vocoder_precision", C.c_int32), ("fft_layers", C.c_int32), ("fft_kernel_size", C.c_int32),
-        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32)]
+        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32), ("decoder_fp32", C.c_int32)]
 
 
 class DttsError(RuntimeError):

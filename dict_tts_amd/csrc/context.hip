@@ -138,7 +138,7 @@ struct dtts_ctx {
     float *weo = nullptr, *dur = nullptr, *pron_attn = nullptr, *dict_attn = nullptr, *context = nullptr, *x_mask = nullptr;
     int64_t* m2w = nullptr;
     int *mel_lens = nullptr, *lens = nullptr;
-    TimerSlot timers[3];
+    TimerSlot timers[DTTS_TIMER_COUNT];
     // ---- resident dictionary table (dtts_dict_table_upload)
     int t_entries = 0;
     int *t_off = nullptr, *t_poff = nullptr, *t_pmmax = nullptr;
@@ -404,15 +404,16 @@ bool build_encoder(dtts_ctx* h, Need& need, Encoder& E, const std::string& p) {
     return E.lg && E.lb;
 }
 
-bool build_wn(dtts_ctx* h, Need& need, WNet& W, const std::string& p, int hidden, int k, int layers) {
+// eng: ENG_F32 (exact fp32 MFMA, generic kernel) or ENG_BF16X3 (split operands: the vconv kernel's WaveNet form)
+bool build_wn(dtts_ctx* h, Need& need, WNet& W, const std::string& p, int hidden, int k, int layers, int eng = ENG_F32) {
     W.hidden = hidden;
     W.layers = layers;
     W.in.resize(layers);
     W.rs.resize(layers);
     for (int i = 0; i < layers; ++i) {
-        if (!pack_plain(h, need, W.in[i], ENG_F32, p + ".in_layers." + std::to_string(i), 1, 1, (k - 1) / 2, true, hidden))
+        if (!pack_plain(h, need, W.in[i], eng, p + ".in_layers." + std::to_string(i), 1, 1, (k - 1) / 2, true, hidden))
             return false;
-        if (!pack_plain(h, need, W.rs[i], ENG_F32, p + ".res_skip_layers." + std::to_string(i), 1, 1, 0)) return false;
+        if (!pack_plain(h, need, W.rs[i], eng, p + ".res_skip_layers." + std::to_string(i), 1, 1, 0)) return false;
     }
     return pack_plain(h, need, W.cond, ENG_F32, p + ".cond_layer", 1, 1, 0);
 }
@@ -487,7 +488,10 @@ int build_acoustic(dtts_ctx* h) {
     }
     if (ok && parity != 0) return fail(h, DTTS_E_INVAL, "odd number of flow blocks is not supported");
     ok = ok && pack_transposed(h, need, h->dec_pre, ENG_F32, m + "fvae.decoder.pre_net.0", 4, 0);
-    ok = ok && build_wn(h, need, h->dec_wn, m + "fvae.decoder.wn", c.fvae_enc_dec_hidden, c.fvae_kernel_size, c.fvae_dec_n_layers);
+    // the decoder WaveNet carries 4.09 of the acoustic model's 4.69 MFLOP per frame: split-bf16 operands (three bf16 MFMAs
+    // per product = 5.3x the fp32-MFMA rate, mel error ~3e-5 against the 1e-3 gate) unless the hidden width does not tile
+    const int dec_eng = (c.fvae_enc_dec_hidden % 64 == 0 && !c.decoder_fp32) ? ENG_BF16X3 : ENG_F32;
+    ok = ok && build_wn(h, need, h->dec_wn, m + "fvae.decoder.wn", c.fvae_enc_dec_hidden, c.fvae_kernel_size, c.fvae_dec_n_layers, dec_eng);
     ok = ok && pack_plain(h, need, h->dec_out, ENG_F32, m + "fvae.decoder.out_proj", 1, 1, 0);
     if (!ok) {
         if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
@@ -574,6 +578,48 @@ int build_vocoder(dtts_ctx* h) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// vconv parameter blocks (vocoder convolutions and the decoder's split-operand WaveNet layers)
+// -DDTTS_ABLATE builds: phase-ablation bits for the vocoder kernels, read ONCE when the library is loaded (never per launch)
+#ifdef DTTS_ABLATE
+static const int g_ablate = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
+#else
+constexpr int g_ablate = 0;
+#endif
+
+VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* lens, int B, int T) {
+    VConvParams p;
+    memset(&p, 0, sizeof p);
+    p.x = x;
+    p.ldx = L.C_in_pad;
+    p.w = (const uint4*)L.w_hi;
+    p.bias = L.bias;
+    p.lens = lens;
+    p.B = B;
+    p.T = T;
+    p.C_in_pad = L.C_in_pad;
+    p.C_out = L.C_out;
+    p.C_out_pad = L.C_out_pad;
+    p.K = L.K;
+    p.dil = L.dil;
+    p.pad = L.pad;
+    p.slope = 1.f;
+    p.div = 1.f;
+    p.in_slope = 1.f;
+    p.C_in = L.C_in;
+    p.dbg = g_ablate & 15;
+    return p;
+}
+// waveform-exact form: fp32 input [B][T][ld] (leaky_relu(in_slope) applied while staging), hi/lo split operands
+VConvParams vparams_x3(const PackedConv& L, const float* xf, int ld, float in_slope, const int* lens, int B, int T) {
+    VConvParams p = vparams(L, nullptr, lens, B, T);
+    p.xf = xf;
+    p.ldx = ld;
+    p.in_slope = in_slope;
+    p.wlo = (const uint4*)L.w_lo;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launch helpers
 struct Timed {
     dtts_ctx* h;
@@ -596,9 +642,11 @@ struct Timed {
         t.launches += 1;
         (void)hipEventRecord(e0, s);
     }
-    ~Timed() {
+    void stop() {   // close the span now (the destructor closes it at scope exit otherwise)
         if (e1) (void)hipEventRecord(e1, s);
+        e1 = nullptr;
     }
+    ~Timed() { stop(); }
 };
 
 ConvParams base_params(const float* x, int ldx, int B, int T_in, int T_out, float* y, int ldy) {
@@ -668,6 +716,48 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
         LAUNCH(conv1d_launch(W.cond, p, s));
     }
     for (int i = 0; i < W.layers; ++i) {
+        if (W.in[i].engine == ENG_BF16X3) {   // split-operand WaveNet layer on the vconv kernel (vconv.hip: WaveNet epilogue)
+            {   // acts = tanh(in(x) + cond_t) * sigmoid(in(x) + cond_s)
+                VConvParams v = vparams_x3(W.in[i], x, H, 1.f, nullptr, B, T);
+                v.bias = nullptr;
+                v.gbias = W.in[i].bias;
+                v.gate_H = H;
+                v.cond = cond;
+                v.ld_cond = 2 * H * W.layers;
+                v.cond_coff = i * 2 * H;
+                v.yf = acts;
+                v.ldyf = H;
+                LAUNCH(vconv_launch(v, s));
+            }
+            {   // res / skip: x += rs[:H], out (+)= rs[H:]  (the last layer has the skip half only)
+                VConvParams v = vparams_x3(W.rs[i], acts, H, 1.f, nullptr, B, T);
+                v.bias = nullptr;
+                v.gbias = W.rs[i].bias;
+                if (i < W.layers - 1) {
+                    v.split = H;
+                    v.yf = x;
+                    v.ldyf = H;
+                    v.res = x;
+                    v.ldres = H;
+                    v.yf2 = out;
+                    v.ldyf2 = H;
+                    if (i > 0) {
+                        v.res_b = out;
+                        v.ldres_b = H;
+                    }
+                } else {
+                    v.split = 1 << 30;   // single segment through the same epilogue
+                    v.yf = out;
+                    v.ldyf = H;
+                    if (i > 0) {
+                        v.res = out;
+                        v.ldres = H;
+                    }
+                }
+                LAUNCH(vconv_launch(v, s));
+            }
+            continue;
+        }
         p = base_params(x, H, B, T, T, acts, H);
         p.cond = cond;
         p.ld_cond = 2 * H * W.layers;
@@ -697,13 +787,6 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
 // leaky_relu copy the next convolution consumes (written by the producer's epilogue).
 namespace {
 
-// -DDTTS_ABLATE builds: phase-ablation bits for the vocoder kernels, read ONCE when the library is loaded (never per launch)
-#ifdef DTTS_ABLATE
-static const int g_ablate = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
-#else
-constexpr int g_ablate = 0;
-#endif
-
 struct StageMult { int m[9]; };  // cumulative upsampling factor per stage, passed by value (no H2D copy on the stream)
 __global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int T, int n_stage, StageMult mult) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -712,39 +795,6 @@ __global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int
     int l = lens ? lens[b] : T;
     l = l < 0 ? 0 : (l > T ? T : l);
     out[i] = l * mult.m[sidx];
-}
-
-VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* lens, int B, int T) {
-    VConvParams p;
-    memset(&p, 0, sizeof p);
-    p.x = x;
-    p.ldx = L.C_in_pad;
-    p.w = (const uint4*)L.w_hi;
-    p.bias = L.bias;
-    p.lens = lens;
-    p.B = B;
-    p.T = T;
-    p.C_in_pad = L.C_in_pad;
-    p.C_out = L.C_out;
-    p.C_out_pad = L.C_out_pad;
-    p.K = L.K;
-    p.dil = L.dil;
-    p.pad = L.pad;
-    p.slope = 1.f;
-    p.div = 1.f;
-    p.in_slope = 1.f;
-    p.C_in = L.C_in;
-    p.dbg = g_ablate & 15;
-    return p;
-}
-// waveform-exact form: fp32 input [B][T][ld] (leaky_relu(in_slope) applied while staging), hi/lo split operands
-VConvParams vparams_x3(const PackedConv& L, const float* xf, int ld, float in_slope, const int* lens, int B, int T) {
-    VConvParams p = vparams(L, nullptr, lens, B, T);
-    p.xf = xf;
-    p.ldx = ld;
-    p.in_slope = in_slope;
-    p.wlo = (const uint4*)L.w_lo;
-    return p;
 }
 
 // exact = DTTS_VOC_F16: fp32 tensors between kernels (no 16-bit copies), serial convolutions on split operands, ResBlock
@@ -1222,6 +1272,7 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     hipStream_t s = (hipStream_t)stream;
     const dtts_config& c = h->cfg;
     const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
+    Timed t_voc(h, DTTS_TIMER_STAGE_HIFIGAN, s);   // 'hifigan' (vocoders/hifigan.py:59): the generator forward
     if (c.vocoder_precision != DTTS_VOC_BF16X3) return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
@@ -1369,6 +1420,11 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     h->T_w = T_w;
     h->L_k = L_k;
     h->P = P;
+    // stage spans under the reference's profile_infer names (modules/dict_tts/model.py:50,86): 'encoder' = this whole call's
+    // device work (dictionary encoder, duration predictor, length regulator; the gather-expand runs in decode here),
+    // 'dict_encoder' = embedding + both relative-position encoders + S2PA
+    Timed t_encoder(h, DTTS_TIMER_STAGE_ENCODER, s);
+    Timed t_dict(h, DTTS_TIMER_STAGE_DICT_ENCODER, s);
     // A1: embedding * sqrt(hidden), lengths
     LAUNCH(embed_launch(word_tokens, h->word_emb, sqrtf((float)C), x, h->lens, B, T_w, C, c.word_size, s));
     // A2: semantic encoder
@@ -1430,6 +1486,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     // A4: linguistic encoder; * (word_tokens > 0) is the same prefix mask
     rc = run_encoder(h, h->lin, x, hb, qkv, att, ff, h->weo, h->lens, B, T_w, s);
     if (rc) return rc;
+    t_dict.stop();
     // A5: duration predictor
     LAUNCH(rowcount_nonzero_launch(h->weo, ilens, B, T_w, C, s));
     {
@@ -1559,6 +1616,7 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
     const int B = h->B, T = h->T_mel, T4 = T / 4, C = c.hidden_size, Z = c.latent_size;
     const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
     const size_t mrows = (size_t)B * T, qrows = (size_t)B * T4;
+    Timed t_fvae(h, DTTS_TIMER_STAGE_FVAE, s);   // 'fvae' (model.py:57) + the gather-expand of run_text_encoder
     Arena& A = h->a_dec;
     // (m2w and x_mask were allocated first by encode; everything below is re-allocated after them on every call)
     A.off = 0;
@@ -1723,7 +1781,7 @@ int dtts_length_regulate(dtts_handle h, const float* dur, const int32_t* ilens, 
 }
 
 int dtts_timer_enable(dtts_handle h, int which) {
-    if (!h || which < 1 || which > 2) return DTTS_E_INVAL;
+    if (!h || which < 1 || which >= DTTS_TIMER_COUNT) return DTTS_E_INVAL;
     h->timers[which].enabled = true;
     return DTTS_OK;
 }
@@ -1737,7 +1795,7 @@ static void timer_collect(TimerSlot& t) {
 }
 
 int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches) {
-    if (!h || which < 1 || which > 2) return DTTS_E_INVAL;
+    if (!h || which < 1 || which >= DTTS_TIMER_COUNT) return DTTS_E_INVAL;
     HIPCHK(hipDeviceSynchronize());
     TimerSlot& t = h->timers[which];
     timer_collect(t);

@@ -25,6 +25,17 @@ struct VConvParams {
     int ldres;
     const float* res2;
     int ldres2;
+    // WaveNet forms (the FVAE decoder's layers on split operands, X3 only)
+    int gate_H;               // > 0: packed co-tiles alternate (tanh tile, sigmoid tile); out[c] = tanh(a_t + b_t + cond_t) * sigmoid(a_s + b_s + cond_s),
+                              //      c < gate_H; bias / gbias are in LOGICAL order [tanh gate_H | sigmoid gate_H] and read through gbias
+    const float* gbias;
+    const float* cond;        // gated: conditioning [B][T][ld_cond], channels cond_coff + (c | gate_H + c)
+    int ld_cond, cond_coff;
+    int split;                // > 0: output channels >= split go to the second segment (column - split): WaveNet res / skip
+    float* yf2;
+    int ldyf2;
+    const float* res_b;       // residual of the second segment
+    int ldres_b;
     float div;                // 1 or num_kernels (true division)
     int post_tanh;
     int dbg;                  // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging

@@ -193,6 +193,71 @@ __global__ __launch_bounds__(256, X3 ? 2 : (NT == 1 ? 3 : 2)) void vconv_kernel(
     // quad).  Stored straight from that layout every wave instruction would touch 32 different rows with 32 B each;
     // instead each 32-row slab goes through LDS (the activation tile is dead by now) and leaves as whole rows:
     // consecutive lanes -> consecutive 16 B of one row, for the residual loads and both stores.
+    if constexpr (X3) {
+        if (p.gate_H || p.split) {
+            // ---- WaveNet epilogue (FVAE decoder layers): whole rows through LDS as below; a thread owns 4 consecutive logical
+            // channels of one row.  Gated: the tanh quad and its sigmoid partner sit 32 columns apart in the staged row.
+            constexpr int EP = CO_T * 4 + 16;
+            constexpr int F4 = CO_T / 4, TOTAL = WT * 32 * F4, PER = TOTAL / 256;
+            const int co_blk = blockIdx.y * CO_T;
+            const int n_out = p.gate_H ? p.gate_H : p.C_out;
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m) __syncthreads();
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e];
+                        *(f32x4*)(smem + (wt * 32 + (lane & 31)) * EP + col * 4) = v;
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int idx = tid + u * 256;
+                    const int rl = idx / F4, c4 = idx % F4;
+                    const int t = t0 + ((rl >> 5) * MT + m) * 32 + (rl & 31);
+                    const int pcol = co_blk + c4 * 4;       // packed column of this quad
+                    int co = pcol;
+                    bool active = true;
+                    if (p.gate_H) {
+                        active = !((pcol >> 5) & 1);        // tanh tiles produce the output; sigmoid tiles are read as partners
+                        co = (pcol >> 6) * 32 + (pcol & 31);
+                    }
+                    if (!(active && t < len && co < n_out)) continue;
+                    const long long row = (long long)b * p.T + t;
+                    f32x4 o = *(const f32x4*)(smem + rl * EP + c4 * 16);
+                    if (p.gate_H) {
+                        f32x4 g = *(const f32x4*)(smem + rl * EP + (c4 + 8) * 16);
+                        o += *(const f32x4*)(p.gbias + co);
+                        g += *(const f32x4*)(p.gbias + p.gate_H + co);
+                        if (p.cond) {
+                            const float* c = p.cond + row * p.ld_cond + p.cond_coff;
+                            o += *(const f32x4*)(c + co);
+                            g += *(const f32x4*)(c + p.gate_H + co);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]) * (1.f / (1.f + expf(-g[e])));
+                    } else if (p.gbias) {
+                        o += *(const f32x4*)(p.gbias + co);
+                    }
+                    if (p.split && co >= p.split) {
+                        const int cs = co - p.split;
+                        if (p.res_b) o += *(const f32x4*)(p.res_b + row * p.ldres_b + cs);
+                        *(f32x4*)(p.yf2 + row * p.ldyf2 + cs) = o;
+                    } else {
+                        if (p.res) o += *(const f32x4*)(p.res + row * p.ldres + co);
+                        *(f32x4*)(p.yf + row * p.ldyf + co) = o;
+                    }
+                }
+            }
+            return;
+        }
+    }
     if ((p.C_out & 3) == 0) {
         constexpr int EP = CO_T * 4 + 16;  // bytes per staged row (+16: conflict-free ds_write_b128)
         constexpr int F4 = CO_T / 4, TOTAL = WT * 32 * F4, PER = TOTAL / 256;
@@ -295,6 +360,7 @@ static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
         configured = lds;
     }
     if (p.C_out_pad % CO_T || p.C_in_pad % CK) return hipErrorInvalidValue;
+    if (p.gate_H && (CO_T % 64)) return hipErrorInvalidValue;   // a tanh tile and its sigmoid partner must sit in one workgroup
     dim3 grid((p.T + TT - 1) / TT, p.C_out_pad / CO_T, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
@@ -311,21 +377,22 @@ static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
 
 hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
     const int ci = p.C_in_pad, co = p.C_out_pad;
+    if ((p.gate_H || p.split) && !p.xf) return hipErrorInvalidValue;   // the WaveNet epilogue exists on the split-operand path only
     if (co % 256 == 0) {
         if (ci % 128 == 0) return vlaunch<4, 2, 1, 4, 128>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
         return vlaunch<4, 2, 1, 4, 32>(p, stream);
     }
-    if (co == 128) {
+    if (co % 128 == 0) {
         if (ci % 128 == 0) return vlaunch<4, 1, 1, 4, 128>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 1, 1, 4, 64>(p, stream);
         return vlaunch<4, 1, 1, 4, 32>(p, stream);
     }
-    if (co == 64) {
+    if (co % 64 == 0) {
         if (ci % 64 == 0) return vlaunch<4, 1, 2, 2, 64>(p, stream);
         return vlaunch<4, 1, 2, 2, 32>(p, stream);
     }
-    if (co == 32) {
+    if (co % 32 == 0) {
         if (ci % 64 == 0) return vlaunch<4, 1, 4, 1, 64>(p, stream);
         return vlaunch<4, 1, 4, 1, 32>(p, stream);
     }

@@ -94,6 +94,7 @@ typedef struct dtts_config {
     int32_t fft_use_pos_embed;        /* FFTBlocks(use_pos_embed=True)                                        */
     int32_t fft_use_last_norm;        /* FFTBlocks(use_last_norm=True)                                        */
     int32_t vocoder_unfused;          /* testing aid, DTTS_VOC_BF16 only: 1 = one kernel per convolution instead of the fused ResBlock kernels */
+    int32_t decoder_fp32;             /* 1 = FVAE decoder WaveNet on exact fp32 MFMA (round 1); 0 (default) = bf16 hi/lo split operands */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
@@ -250,6 +251,12 @@ int dtts_wav_to_int16(dtts_handle h, const float* wav_dev, const int32_t* lens_d
  */
 #define DTTS_TIMER_VOC_CONV 1   /* the vocoder's MFMA convolution kernel (dominant kernel) */
 #define DTTS_TIMER_S2PA 2       /* the S2PA dictionary-attention kernel                    */
+/* stage spans under the names of the reference's profile_infer timers (utils.Timer): one event pair per call, launches = calls */
+#define DTTS_TIMER_STAGE_ENCODER 3      /* 'encoder'      modules/dict_tts/model.py:50  = dtts_text2mel_encode* (device span, incl. the T_mel sync wait) */
+#define DTTS_TIMER_STAGE_DICT_ENCODER 4 /* 'dict_encoder' modules/dict_tts/model.py:86  = embedding, both encoders, S2PA                                   */
+#define DTTS_TIMER_STAGE_FVAE 5         /* 'fvae'         modules/dict_tts/model.py:57  = dtts_text2mel_decode (gather-expand + prior flow + decoder)       */
+#define DTTS_TIMER_STAGE_HIFIGAN 6      /* 'hifigan'      vocoders/hifigan.py:59        = dtts_hifigan_forward                                              */
+#define DTTS_TIMER_COUNT 7
 int dtts_timer_enable(dtts_handle h, int which);
 int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches); /* synchronises */
 int dtts_timer_reset(dtts_handle h);
