@@ -128,6 +128,8 @@ struct dtts_ctx {
     std::vector<std::vector<PackedConv>> rb1, rb2;  // [resblock][3]
     std::vector<std::vector<PackedConv>> rbf1, rbf2;  // fused-ResBlock copies (taps zero padded), empty where unsupported
     int hop = 1;
+    int tune = 0;
+    float *post_w = nullptr, *post_b = nullptr;   // conv_post as [taps][C] fp32 for the fused epilogue of the last ResBlock (rblock.hip), or null
     // ---- workspaces and per-call state
     Arena a_enc, a_dec, a_voc;
     unsigned* amax_bits = nullptr;  // dtts_wav_to_int16 scratch
@@ -349,7 +351,11 @@ bool pack_transposed(dtts_ctx* h, Need& need, PackedConv& L, int engine, const s
     for (int r = 0; r < u; ++r)
         for (int co = 0; co < C_out; ++co) bias[(size_t)r * C_out + co] = b0[co];
     const float* pw = w->f.data();
-    return pack_conv(
+    // k = 2u, pad = u/2 (HifiGAN's upsamplers): phase r < u/2 reads input offsets {-1, 0}, r >= u/2 reads {0, +1} — a third
+    // of the 3-tap polyphase weights are structural zeros and the kernel skips them per wave (vconv.hip: poly_half)
+    const int cop = u * C_out, wave_ch = (cop % 256 == 0) ? 64 : 32;   // channels per wave of the vconv configuration this layer gets
+    const bool half = !single && k == 2 * u && 2 * p == u && (cop / 2) % wave_ch == 0;
+    const bool ok = pack_conv(
         h, L, engine, u * C_out, C_in, K,
         [=](int pco, int ci, int tap) {
             const int r = pco / C_out, co = pco % C_out, delta = tap - pad;
@@ -357,6 +363,8 @@ bool pack_transposed(dtts_ctx* h, Need& need, PackedConv& L, int engine, const s
             return (j >= 0 && j < k) ? pw[((size_t)ci * C_out + co) * k + j] : 0.f;
         },
         bias, 1, 1, pad, 0, 2.0 * C_in * C_out * k /* per INPUT row: u outputs x k/u taps */);
+    L.poly_half = (half && !(h->tune & 2)) ? 1 : 0;
+    return ok;
 }
 
 float* upload_named(dtts_ctx* h, Need& need, const std::string& name) {
@@ -568,6 +576,22 @@ int build_vocoder(dtts_ctx* h) {
         }
     }
     ok = ok && pack_plain(h, need, h->conv_post, eng, v + "conv_post", 1, 1, 3);
+    {   // conv_post (C -> 1, k = 7) + tanh fused into the last stage's last ResBlock kernel when that stage runs on rblock at C = 32
+        const int last_ch = c.upsample_initial_channel >> c.n_upsamples;
+        const HostTensor* w = ok ? folded_weight(h, need, v + "conv_post") : nullptr;
+        const std::vector<float> b = ok ? bias_of(need, v + "conv_post") : std::vector<float>();
+        bool fusable = ok && eng_rb != ENG_BF16X3 && last_ch == 32 && w && w->shape.size() == 3 && w->shape[0] == 1 && w->shape[1] == 32 &&
+                       w->shape[2] == 7 && b.size() == 1 && nk >= 2;
+        for (int j = 0; fusable && j < nk; ++j) fusable = !h->rbf1[(size_t)(c.n_upsamples - 1) * nk + j].empty();
+        if (fusable && !(h->tune & 1)) {
+            std::vector<float> wt((size_t)7 * 32);
+            for (int ci = 0; ci < 32; ++ci)
+                for (int k = 0; k < 7; ++k) wt[(size_t)k * 32 + ci] = w->f[(size_t)ci * 7 + k];
+            h->post_w = upload(h, wt);
+            h->post_b = upload(h, b);
+            ok = h->post_w && h->post_b;
+        }
+    }
     if (!ok) {
         if (!need.missing.empty()) return fail(h, DTTS_E_NOENT, "missing weight tensor '%s'", need.missing.c_str());
         if (h->err.empty()) return fail(h, DTTS_E_NOMEM, "packing / uploading vocoder weights failed");
@@ -606,6 +630,7 @@ VConvParams vparams(const PackedConv& L, const unsigned short* x, const int* len
     p.div = 1.f;
     p.in_slope = 1.f;
     p.C_in = L.C_in;
+    p.poly_half = L.poly_half;
     p.dbg = g_ablate & 15;
     return p;
 }
@@ -839,6 +864,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
     const int TV = DTTS_TIMER_VOC_CONV;
     const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)
+    bool post_done = false;
     int Tcur = T, ch = c.upsample_initial_channel;
     if (exact) {   // conv_pre: mel fp32 in, fp32 out
         VConvParams p = vparams_x3(h->conv_pre, mel, c.audio_num_mel_bins, 1.f, lensS, B, T);
@@ -909,6 +935,13 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 rp.slope = last_stage ? 0.01f : 0.1f;
                 rp.Sa = exact ? nullptr : Sa;
                 rp.drop_S = exact ? 0 : 1;   // bf16 mode: after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1] / conv_post)
+                if (last_stage && j == nk - 1 && h->post_w) {   // conv_post + tanh in this kernel's epilogue: the stage output stays on chip
+                    rp.wav = wav;
+                    rp.post_w = h->post_w;
+                    rp.post_b = h->post_b;
+                    rp.Sa = nullptr;
+                    post_done = true;
+                }
                 rp.el = el;
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
@@ -991,7 +1024,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
             }
         }
     }
-    {   // wav = tanh(conv_post(leaky_relu(x, 0.01)))
+    if (!post_done) {   // wav = tanh(conv_post(leaky_relu(x, 0.01)))
         VConvParams p = exact ? vparams_x3(h->conv_post, Sf, ch, 0.01f, lensS + (size_t)nup * B, B, Tcur)
                               : vparams(h->conv_post, Sa, lensS + (size_t)nup * B, B, Tcur);
         p.yf = wav;
@@ -1069,6 +1102,9 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
         return fail(nullptr, DTTS_E_INVAL, "dtts_create: unsupported configuration");
     dtts_ctx* h = new dtts_ctx();
     h->cfg = *cfg;
+    // same-box A/B switches for tuning, read ONCE per context (never on the launch path): bit 0 = conv_post as its own kernel,
+    // bit 1 = upsamplers without the zero-tap skip
+    h->tune = getenv("DTTS_TUNE") ? atoi(getenv("DTTS_TUNE")) : 0;
     *out = h;
     return DTTS_OK;
 }

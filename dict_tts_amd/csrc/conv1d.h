@@ -60,6 +60,8 @@ struct PackedConv {
     int C_in = 0, C_in_pad = 0, C_out = 0, C_out_pad = 0, K = 1, CK = 64;
     int dil = 1, stride = 1, pad = 0;
     int gate_H = 0;
+    int poly_half = 0;        // polyphase form of a k = 2u, pad = u/2 transposed convolution: packed channels of the first half of the
+                              // phases have an all-zero LAST tap, those of the second half an all-zero FIRST tap (context.hip:pack_transposed)
     double flops_per_row = 0; // algorithmic 2*MAC per output row (unpadded), for the roofline report
 };
 

@@ -21,6 +21,10 @@ struct RBlockParams {
     int mode;              // 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
     int drop_S;            // mode 2 with Sa: do not write the fp32 xs (nothing reads it after the stage)
     float div, slope;
+    // fused conv_post + tanh (last stage, mode 2, C = 32): the stage output never reaches HBM, the waveform is written instead
+    float* wav;            // [B][T] or null
+    const float* post_w;   // conv_post weight as [7 taps][C] fp32
+    const float* post_b;   // [1]
     int el;                // 16-bit operand type: EL_BF16 (rb_common.h) or EL_F16; the packed weights are in that type
     int dbg;               // -DDTTS_ABLATE builds only; tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };

@@ -13,6 +13,8 @@
 #include "rblock.h"
 #include "rb_common.h"
 
+#include <algorithm>
+
 namespace dtts {
 
 template <int C, int MT, int NT, int WT, int WC, int EL>
@@ -33,9 +35,13 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
     const int b = blockIdx.y;
     const int H = 6 * (p.K - 1);
     const int TT = W - 2 * H;
-    const int t0 = blockIdx.x * TT;
+    // fused conv_post (p.wav): the tile's TT valid rows give TT - (PK - 1) output samples, so tiles step by that and start
+    // (PK - 1) / 2 rows early
+    constexpr int PK = 7, PH = (PK - 1) / 2;
+    const int TTo = p.wav ? TT - 2 * PH : TT;
+    const int t0 = blockIdx.x * TTo - (p.wav ? PH : 0);
     const int len = p.lens ? p.lens[b] : p.T;
-    if (t0 >= len) return;
+    if (t0 + (p.wav ? PH : 0) >= len) return;
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;
 
@@ -182,6 +188,11 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
             sold[m][u] = u32x4{0u, 0u, 0u, 0u};
             if (p.mode >= 1) sold[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0);
         }
+    // fused conv_post: the stage output leaky_relu(xs / num_kernels) stays in LDS as an fp32 tile ([TT rows][C], rows outside
+    // the utterance zero = conv_post's zero padding) instead of going to HBM; the transposition buffer moves behind it
+    constexpr int OP = C * 4;                      // otile row pitch (bytes)
+    char* otile = smem;
+    char* estage = p.wav ? smem + (((size_t)TT * OP > (size_t)(W + 2 * RB_GUARD) * PITCH) ? (size_t)TT * OP : (size_t)(W + 2 * RB_GUARD) * PITCH) : stage;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (m) __syncthreads();
@@ -192,14 +203,24 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = xr[m][n][4 * q + e];
-                *(f32x4*)(stage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+                *(f32x4*)(estage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
             }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(stage + (r0 + 32 * u) * EP + c4 * 16);
+            f32x4 o = *(const f32x4*)(estage + (r0 + 32 * u) * EP + c4 * 16);
             o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
+            if (p.wav) {
+                const int row = (u * MT + m) * 32 + r0;                // local tile row
+                if (row >= H && row < H + TT) {
+                    const int t = base_t + row;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (t >= 0 && t < len) ? lrelu(o[e] / p.div, p.slope) : 0.f;
+                    *(f32x4*)(otile + (size_t)(row - H) * OP + c4 * 16) = o;
+                }
+                continue;
+            }
             if (p.mode == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
@@ -213,6 +234,33 @@ __global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams
             }
         }
     }
+    if constexpr (C == 32) if (p.wav) {   // (the launcher rejects p.wav for other widths)
+        // ---- wav[t] = tanh(b + sum_{tap, c} w[c][tap] * otile[t + tap - 3][c])   (conv_post + tanh, hifigan.py:139-141) in exact fp32:
+        // 8 lanes per output sample (4 channels each, 7 taps), partial sums joined by three xor-shuffles
+        __syncthreads();
+        const int q8 = tid & 7, rr = tid >> 3;                         // channel quad, row within a pass of THREADS / 8 rows
+        f32x4 wq[PK];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) wq[k] = *(const f32x4*)(p.post_w + k * C + q8 * 4);
+        const float pb = p.post_b[0];
+        float* wb = p.wav + brow;
+        for (int o0 = 0; o0 < TTo; o0 += THREADS / 8) {
+            const int o = o0 + rr;                                     // output index within the tile: otile rows o .. o + PK - 1
+            float a = 0.f;
+            if (o < TTo) {
+#pragma unroll
+                for (int k = 0; k < PK; ++k) {
+                    const f32x4 v = *(const f32x4*)(otile + (size_t)(o + k) * OP + q8 * 16);
+                    a += v[0] * wq[k][0] + v[1] * wq[k][1] + v[2] * wq[k][2] + v[3] * wq[k][3];
+                }
+            }
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            const int t = t0 + PH + o;
+            if (q8 == 0 && o < TTo && t < len) wb[t] = tanhf(a + pb);
+        }
+    }
 }
 
 template <int C, int MT, int NT, int WT, int WC, int EL>
@@ -220,7 +268,13 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
     const int H = 6 * (p.K - 1), TT = W - 2 * H;
     if (TT < 32) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
+    size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
+    int TTo = TT;
+    if (p.wav) {   // fused conv_post (7 taps): the fp32 output tile may be larger than the activation tile it replaces
+        if (C != 32 || p.mode != 2 || !p.post_w || !p.post_b) return hipErrorInvalidValue;
+        lds = std::max((size_t)TT * C * 4, (size_t)(W + 2 * RB_GUARD) * PITCH) + (size_t)WT * 32 * EP;
+        TTo = TT - 6;
+    }
     auto kern = rblock_kernel<C, MT, NT, WT, WC, EL>;
     static bool configured = false;
     if (!configured) {
@@ -228,7 +282,7 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    dim3 grid((p.T + TT - 1) / TT, p.B);
+    dim3 grid((p.T + TTo - 1) / TTo, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WT * WC), lds, stream, p);
     return hipGetLastError();
 }

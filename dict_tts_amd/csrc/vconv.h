@@ -36,6 +36,7 @@ struct VConvParams {
     int ldyf2;
     const float* res_b;       // residual of the second segment
     int ldres_b;
+    int poly_half;            // PackedConv::poly_half: waves in the first half of the packed channels skip the last tap, the others the first
     float div;                // 1 or num_kernels (true division)
     int post_tanh;
     int dbg;                  // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging

@@ -71,8 +71,15 @@ __global__ __launch_bounds__(256, X3 ? 2 : (NT == 1 ? 3 : 2)) void vconv_kernel(
     const long long wlo_d = X3 ? (const char*)p.wlo - (const char*)p.w : 0;   // the lo pack mirrors the hi pack: one pointer walks both
     auto wlo = [&](const uint4* q) { return *(const uint4*)((const char*)q + wlo_d); };
     const uint4* wpf = p.w + (size_t)ct0 * 64 + lane;
+    // polyphase upsamplers (k = 2u): this wave's channels use two of the three taps (the third is all zero)
+    int tap_lo = 0, tap_hi = p.K;
+    if (p.poly_half) {
+        const bool second = ct0 * 32 >= (p.C_out_pad >> 1);
+        tap_lo = second ? 1 : 0;
+        tap_hi = second ? p.K : p.K - 1;
+    }
     auto preload = [&](int ci0) {
-        wpf = p.w + ((size_t)(ci0 >> 4) * NCT + ct0) * 64 + lane;
+        wpf = p.w + (((size_t)tap_lo * NG + (ci0 >> 4)) * NCT + ct0) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
 #pragma unroll
@@ -143,13 +150,13 @@ __global__ __launch_bounds__(256, X3 ? 2 : (NT == 1 ? 3 : 2)) void vconv_kernel(
         uint4 xa[2][MT], xl[X3 ? 2 : 1][MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            xa[0][m] = *(const uint4*)(smem + xoff + m * 32 * PITCH);
-            if constexpr (X3) xl[0][m] = *(const uint4*)(smem + lo_off + xoff + m * 32 * PITCH);
+            xa[0][m] = *(const uint4*)(smem + xoff + tap_lo * p.dil * PITCH + m * 32 * PITCH);
+            if constexpr (X3) xl[0][m] = *(const uint4*)(smem + lo_off + xoff + tap_lo * p.dil * PITCH + m * 32 * PITCH);
         }
-        const int ntap = DTTS_DBG(p, 1) ? 0 : p.K;
+        const int ntap = DTTS_DBG(p, 1) ? tap_lo : tap_hi;
         const int dilP = p.dil * PITCH;
-        int arow = xoff;
-        for (int tap = 0; tap < ntap; ++tap) {
+        int arow = xoff + tap_lo * dilP;
+        for (int tap = tap_lo; tap < ntap; ++tap) {
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
 #pragma unroll
