@@ -18,7 +18,7 @@
 namespace dtts {
 
 template <int C, int MT, int NT, int WT, int WC, int EL>
-__global__ __launch_bounds__(64 * WT * WC) void rblock_kernel(const RBlockParams p) {
+__global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void rblock_kernel(const RBlockParams p) {
     static_assert(WC * NT * 32 == C, "channel tiling must cover C");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int THREADS = 64 * WT * WC;
