@@ -327,6 +327,7 @@ struct S2paShared {
     unsigned short idx[S2PA_LMAX];
     __attribute__((aligned(16))) float part[S2PA_NW][768];
     float red[2 * S2PA_NW];
+    float wmax[S2PA_NW];
     float sense[16];
     float pw[64];
     int pid[64 + 4];
@@ -509,31 +510,115 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     // a word past the end of its utterance: its weights are still returned (dict_attn), its context is zeroed by the
     // caller whatever the values are, so nothing is read for it
     const bool dead = a.lens && t >= a.lens[b];
-    const int n_val = dead ? 0 : (n ? n : r.Lrow);
-    // logits: a wave takes RU listed rows at a time - 12 independent 16-byte loads per lane before the first reduction
-    for (int i = wave * RU; i < n; i += S2PA_NW * RU) {
-        f32x4 k[RU][S2PA_DMAX4];
-        int lr[RU];
+    // ---- ONE streaming pass over the live rows: a wave takes RU listed rows at a time (12 independent 16-byte loads per lane
+    // and row before the first reduction), computes their logits, and folds exp(logit - m) * value row into a running
+    // weighted sum with a running maximum m (the online-softmax recurrence), so the value rows are not re-read after the
+    // softmax: when the table stores value == key (the reference does, binarizer_zh.py:232-233) a row is read once.
+    // The four waves' partial sums are merged with the block-level maximum / normaliser of the full softmax below, which is
+    // still computed from the stored logits exactly as before (dict_attn, the sense merge and the pinyin mix use it).
+    const bool alias = r.kb == r.vb;
+    float m_run = -3.0e38f;
+    f32x4 acc[S2PA_DMAX4];
 #pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            lr[j] = sh.idx[min(i + j, n - 1)];
-            const f32x4* kr = r.kb + (long long)lr[j] * D4;
+    for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fold = [&](const float (&lg)[RU], const f32x4 (&v)[RU][S2PA_DMAX4], int cnt) {
+        float mn = m_run;
 #pragma unroll
-            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-                k[j][cc] = (lane + 64 * cc < D4) ? kr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < RU; ++j)
+            if (j < cnt) mn = fmaxf(mn, lg[j]);
+        const float sc = expf(m_run - mn);
+        float e[RU];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) e[j] = j < cnt ? expf(lg[j] - mn) : 0.f;
+#pragma unroll
+        for (int cc = 0; cc < S2PA_DMAX4; ++cc) {
+            acc[cc] = acc[cc] * sc;
+#pragma unroll
+            for (int j = 0; j < RU; ++j) acc[cc] += v[j][cc] * e[j];
         }
+        m_run = mn;
+    };
+    constexpr int RV = RU / 2;   // rows folded together.  Row -> (wave, fold) assignment is the SAME with and without aliasing (chunk c
+                                 // of RV rows goes to wave c % NW), so the two input forms give bit-identical results
+    if (alias) {
+        // two chunks (c, c + NW) of this wave in flight at once: 2 * RV rows = 12 independent 16-byte loads per lane
+        for (int i = wave * RV; i < n; i += 2 * S2PA_NW * RV) {
+            f32x4 k[2][RU][S2PA_DMAX4];
+            int lr[2][RV];
 #pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            float acc = 0.f;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-                if (lane + 64 * cc < D4) acc += k[j][cc][0] * q[cc][0] + k[j][cc][1] * q[cc][1] + k[j][cc][2] * q[cc][2] + k[j][cc][3] * q[cc][3];
-            acc = wave_sum(acc);
-            if (lane == 0 && i + j < n) sh.lg[lr[j]] = acc;
+                for (int j = 0; j < RV; ++j) {
+                    lr[h][j] = sh.idx[min(i + h * S2PA_NW * RV + j, n - 1)];
+                    const f32x4* kr = r.kb + (long long)lr[h][j] * D4;
+#pragma unroll
+                    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                        k[h][j][cc] = (lane + 64 * cc < D4) ? kr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i0 = i + h * S2PA_NW * RV;
+                if (i0 >= n) break;
+#pragma unroll
+                for (int j = RV; j < RU; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < S2PA_DMAX4; ++cc) k[h][j][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float lg[RU];
+#pragma unroll
+                for (int j = 0; j < RU; ++j) lg[j] = 0.f;
+#pragma unroll
+                for (int j = 0; j < RV; ++j) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                        if (lane + 64 * cc < D4)
+                            d += k[h][j][cc][0] * q[cc][0] + k[h][j][cc][1] * q[cc][1] + k[h][j][cc][2] * q[cc][2] + k[h][j][cc][3] * q[cc][3];
+                    lg[j] = wave_sum(d);
+                    if (lane == 0 && i0 + j < n) sh.lg[lr[h][j]] = lg[j];
+                }
+                if (!dead) fold(lg, k[h], min(n - i0, RV));
+            }
+        }
+    } else {   // keys and values in flight together: one chunk per step
+        for (int i = wave * RV; i < n; i += S2PA_NW * RV) {
+            f32x4 k[RV][S2PA_DMAX4], v[RU][S2PA_DMAX4];
+            int lr[RV];
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                lr[j] = sh.idx[min(i + j, n - 1)];
+                const f32x4* kr = r.kb + (long long)lr[j] * D4;
+                const f32x4* vr = r.vb + (long long)lr[j] * D4;
+#pragma unroll
+                for (int cc = 0; cc < S2PA_DMAX4; ++cc) {
+                    k[j][cc] = (lane + 64 * cc < D4) ? kr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[j][cc] = (lane + 64 * cc < D4 && !dead) ? vr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int j = RV; j < RU; ++j)
+#pragma unroll
+                for (int cc = 0; cc < S2PA_DMAX4; ++cc) v[j][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float lg[RU];
+#pragma unroll
+            for (int j = 0; j < RU; ++j) lg[j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                float d = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                    if (lane + 64 * cc < D4) d += k[j][cc][0] * q[cc][0] + k[j][cc][1] * q[cc][1] + k[j][cc][2] * q[cc][2] + k[j][cc][3] * q[cc][3];
+                lg[j] = wave_sum(d);
+                if (lane == 0 && i + j < n) sh.lg[lr[j]] = lg[j];
+            }
+            if (!dead) fold(lg, v, min(n - i, RV));
         }
     }
+#pragma unroll
+    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+        if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = acc[cc];
+    if (lane == 0) sh.wmax[wave] = m_run;
     __syncthreads();
-    // softmax over l
+    // softmax over l (all L logits: live, masked -1e9, zero-vector 0)
     float mx = -3.0e38f;
     for (int l = tid; l < L; l += S2PA_NTHR) mx = fmaxf(mx, sh.lg[l]);
     mx = s2pa_block_max(sh, mx, tid);
@@ -546,37 +631,42 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     sm = s2pa_block_sum(sh, sm, tid);
     for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = sh.lg[l] / sm;
     __syncthreads();
-    // weighted sum of the value rows (masked rows have weight exactly 0 and rows >= Lrow are zero vectors: only the
-    // listed rows contribute; with no live row the softmax is uniform and the list holds every row)
-    f32x4 acc[S2PA_DMAX4];
+    if (n > 0 || dead) {
+        // context = sum_w exp(m_w - mx) * partial_w / sm  (a wave that saw no row has m_w = -3e38: factor 0)
+        float f[S2PA_NW];
 #pragma unroll
-    for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = wave * RU; i < n_val; i += S2PA_NW * RU) {
-        f32x4 v[RU][S2PA_DMAX4];
-        float w[RU];
+        for (int w = 0; w < S2PA_NW; ++w) f[w] = expf(sh.wmax[w] - mx) / sm;
+        for (int d = tid; d < a.D; d += S2PA_NTHR) {
+            float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < RU; ++j) {
-            const int l = sh.idx[min(i + j, n_val - 1)];
-            w[j] = i + j < n_val ? sh.lg[l] : 0.f;
+            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d] * f[w];   // fixed order: reproducible
+            a.wv[(long long)row * a.D + d] = dead ? 0.f : sum;
+        }
+    } else {
+        // no live row: every logit is masked, the softmax is uniform and every value row of the word contributes (as in the
+        // reference); rare (a fully padded word row inside an utterance), kept as a separate weighted pass
+        const int n_val = r.Lrow;
+        f32x4 va[S2PA_DMAX4];
+#pragma unroll
+        for (int cc = 0; cc < S2PA_DMAX4; ++cc) va[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int l = wave; l < n_val; l += S2PA_NW) {
+            const float w = sh.lg[l];
             const f32x4* vr = r.vb + (long long)l * D4;
 #pragma unroll
             for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-                v[j][cc] = (lane + 64 * cc < D4) ? vr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (lane + 64 * cc < D4) va[cc] += vr[lane + 64 * cc] * w;
         }
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RU; ++j)
+        for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+            if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = va[cc];
+        __syncthreads();
+        for (int d = tid; d < a.D; d += S2PA_NTHR) {
+            float sum = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] += v[j][cc] * w[j];
-    }
-#pragma unroll
-    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-        if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = acc[cc];
-    __syncthreads();
-    for (int d = tid; d < a.D; d += S2PA_NTHR) {
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d];
-        a.wv[(long long)row * a.D + d] = sum;
+            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d];
+            a.wv[(long long)row * a.D + d] = sum;
+        }
     }
     s2pa_tail(sh, a, pre, row, b, t, tid);
 }
