@@ -327,6 +327,7 @@ def main():
             lens, _, _ = run_step(i, mode)
             if lens is not None:
                 lens_acc += lens.sum()
+        state["warm_frames"] = int(lens_acc.item())
         lens_acc.zero_()
         torch.cuda.synchronize()
         voc.ctx.timer_reset()
@@ -345,6 +346,7 @@ def main():
         return time.perf_counter() - t0, int(lens_acc.item())
 
     elapsed, frames_rank = timed_loop(args.steps, args.warmup, args.input)
+    main_warm_frames = state["warm_frames"]
     conv_ms, conv_launches = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
     assert state["last"] is None or (torch.isfinite(state["last"][2]).all() and float(state["last"][2].abs().max()) <= 1.0)
 
@@ -495,6 +497,8 @@ def main():
                        "utterances_per_gpu_per_batch": args.batch, "batches_per_step": steps_per_pass,
                        "distinct_batches": len([b for b in batches if b is not None]), "batch_shapes_B_Tw_Lk": shapes,
                        "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
+                       "all_forwards": {"n": (args.warmup + args.steps) * steps_per_pass,   # what a profiler attached to this run sees
+                                        "mel_frames": main_warm_frames + frames_rank},
                        "step_includes": {"table": "H2D of the batch's ids + device prior sample + int16 conversion + D2H of the int16 waveforms "
                                                   "(dictionary resident in HBM: dtts_dict_table_upload, once)",
                                          "resident": "ids resident in HBM; fp32 waveform left in HBM",

@@ -3,7 +3,7 @@
 databases) of the same `bench.py` command.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for
 wide coalesced reads on gfx950 (calibrated here with tools/voc_bench.py DTTS_CALIB=1: a 256 MiB read reports 128 MiB,
 a 256 MiB fill reports 256 MiB); both counters are in KB.
-usage: pmc_traffic.py fetch.db write.db <vocoder forwards in the profiled run> <valid mel frames per forward>"""
+usage: pmc_traffic.py fetch.db write.db <vocoder forwards in the profiled run> <valid mel frames over ALL those forwards> [precision]"""
 import json
 import sqlite3
 import sys
@@ -27,7 +27,9 @@ def per_kernel(db, counter):
 
 
 def main():
-    fdb, wdb, forwards, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    fdb, wdb, forwards, frames_all = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    prec = sys.argv[5] if len(sys.argv) > 5 else "f16"
+    frames = frames_all / forwards
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     rows, rd, wr = [], 0.0, 0.0
     for n in sorted(f):
@@ -43,7 +45,7 @@ def main():
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py, MI355X; FETCH_SIZE doubled "
                   "per MI355X_MICROARCH.md HBM section; units KB; produced by tools/pmc_traffic.py",
         "kernels": "dtts::vconv_kernel<*> + dtts::vpair_kernel<*> + dtts::rblock_kernel<*> (the HifiGAN convolution family)",
-        "vocoder_forwards_in_profile": forwards, "mel_frames_per_step": frames,
+        "vocoder_precision": prec, "vocoder_forwards_in_profile": forwards, "mel_frames_per_step": frames,
         "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
         "hbm_bytes_per_mel_frame": (rd + wr) / frames, "per_kernel": rows}, indent=1))
 
