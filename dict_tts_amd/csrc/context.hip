@@ -548,7 +548,7 @@ int build_vocoder(dtts_ctx* h) {
     for (int i = 0; ok && eng_rb != ENG_BF16X3 && i < c.n_upsamples * nk; ++i) {
         const int j = i % nk, k = c.resblock_kernel_sizes[j];
         const int ch = c.upsample_initial_channel >> (i / nk + 1);
-        if (!rblock_supported(ch, k)) {
+        if (!rblock_supported(ch, k) || ((h->tune & 8) && ch >= 128)) {   // DTTS_TUNE bit 3: the wide stages' k = 3 ResBlocks per iteration (vpair) again
             bool vp = h->rb1[i][0].C_in_pad == ch;
             for (int mth = 0; mth < 3; ++mth) vp = vp && vpair_supported(ch, k, c.resblock_dilation_sizes[j][mth]);
             if (eng_rb == ENG_F16 && !vp)
@@ -1103,7 +1103,7 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
     dtts_ctx* h = new dtts_ctx();
     h->cfg = *cfg;
     // same-box A/B switches for tuning, read ONCE per context (never on the launch path): bit 0 = conv_post as its own kernel,
-    // bit 1 = upsamplers without the zero-tap skip
+    // bit 1 = upsamplers without the zero-tap skip, bit 3 = no whole-ResBlock fusion at C >= 128
     h->tune = getenv("DTTS_TUNE") ? atoi(getenv("DTTS_TUNE")) : 0;
     *out = h;
     return DTTS_OK;

@@ -57,9 +57,12 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // exactly the zero padding needed, and cost one v_add per access.  All MT*PER 16 B loads of a thread are issued
     // before the first LDS round trip: one exposed HBM latency per tile.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    constexpr int PER = SROWS * F4 / THREADS;
-    static_assert(SROWS * F4 % THREADS == 0 && THREADS / F4 == 32, "one staging pass = 32 rows per thread-row group");
-    const int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, 32)
+    constexpr int RPP = THREADS / F4;              // rows one cooperative access of the workgroup covers (32 at C <= 64, 16 at C >= 128)
+    constexpr int PER = SROWS / RPP;               // accesses per staging pass of SROWS = 32 rows per time-wave
+    static_assert(THREADS % F4 == 0 && SROWS % RPP == 0 && RPP <= 32, "row-coalesced staging");
+    const int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, RPP)
+    // staged row s = r0 + RPP * u of pass m <-> tile row: 32-row slab m of time-wave s / 32
+    auto tile_row = [&](int m, int u) { const int sr = r0 + RPP * u; return ((sr >> 5) * MT + m) * 32 + (sr & 31); };
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + brow * C), 0, len * C * 4, 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
     const int goff0 = ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
@@ -71,13 +74,13 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 ld[m][u] = u32x4{0u, 0u, 0u, 0u};
-                if (!DTTS_DBG(p, 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff0 + (u * MT + m) * (32 * C * 4), 0, 0);
+                if (!DTTS_DBG(p, 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff0 + (tile_row(m, u) - r0) * (C * 4), 0, 0);
             }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             if (m) __syncthreads();
 #pragma unroll
-            for (int u = 0; u < PER; ++u) *(u32x4*)(stage + (r0 + 32 * u) * EP + c4 * 16) = ld[m][u];
+            for (int u = 0; u < PER; ++u) *(u32x4*)(stage + (r0 + RPP * u) * EP + c4 * 16) = ld[m][u];
             __syncthreads();
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Sa ? p.Sa + brow * C : (unsigned short*)(p.S + brow * C)), 0,
                                                         len * C * 2, 0x00020000);
     auto eoff = [&](int m, int u) {
-        const int row = (u * MT + m) * 32 + r0;
-        return (row >= H && row < H + TT) ? goff0 + (u * MT + m) * (32 * C * 4) : (int)0x80000000;
+        const int row = tile_row(m, u);
+        return (row >= H && row < H + TT) ? goff0 + (row - r0) * (C * 4) : (int)0x80000000;
     };
     u32x4 sold[MT][PER];
 #pragma unroll
@@ -209,10 +212,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(estage + (r0 + 32 * u) * EP + c4 * 16);
+            f32x4 o = *(const f32x4*)(estage + (r0 + RPP * u) * EP + c4 * 16);
             o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
             if (p.wav) {
-                const int row = (u * MT + m) * 32 + r0;                // local tile row
+                const int row = tile_row(m, u);                        // local tile row
                 if (row >= H && row < H + TT) {
                     const int t = base_t + row;
 #pragma unroll
@@ -287,7 +290,12 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-bool rblock_supported(int C, int K) { return (C == 32 || C == 64) && K >= 3 && K <= 11 && (K & 1); }
+// whole-ResBlock fusion pays where the halo 6 (k - 1) is small against the tile that fits: every k at C <= 64 (512-row tiles), k = 3
+// at C = 128 (256 rows) and C = 256 (128 rows); the larger kernels of the wide stages run per iteration (vpair.hip)
+bool rblock_supported(int C, int K) {
+    if (!(K & 1) || K < 3 || K > 11) return false;
+    return C == 32 || C == 64 || ((C == 128 || C == 256) && K == 3);
+}
 
 int rblock_padded_taps(int C, int K) {
     const int nkg = C / 16;
@@ -300,6 +308,8 @@ hipError_t rblock_launch(const RBlockParams& p, int C, hipStream_t stream) {
     const bool h = p.el == EL_F16;
     if (C == 32) return h ? rb_launch_cfg<32, 4, 1, 4, 1, EL_F16>(p, stream) : rb_launch_cfg<32, 4, 1, 4, 1, EL_BF16>(p, stream);   // 512-row tile, 4 waves over time
     if (C == 64) return h ? rb_launch_cfg<64, 4, 1, 4, 2, EL_F16>(p, stream) : rb_launch_cfg<64, 4, 1, 4, 2, EL_BF16>(p, stream);   // 512-row tile, 8 waves (4 time x 2 channel)
+    if (C == 128) return h ? rb_launch_cfg<128, 4, 1, 2, 4, EL_F16>(p, stream) : rb_launch_cfg<128, 4, 1, 2, 4, EL_BF16>(p, stream);   // 256-row tile, 8 waves (2 time x 4 channel)
+    if (C == 256) return h ? rb_launch_cfg<256, 4, 1, 1, 8, EL_F16>(p, stream) : rb_launch_cfg<256, 4, 1, 1, 8, EL_BF16>(p, stream);   // 128-row tile, 8 waves over channels
     return hipErrorInvalidValue;
 }
 
