@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
 // staging), split into bf16 hi + lo LDS tiles; weights arrive as hi + lo packs; three MFMAs per step: Wlo*Xhi + Whi*Xlo +
 // Whi*Xhi (16-bit significand products, fp32 accumulation).
 template <int MT, int NT, int WT, int WC, int CK, bool X3>
-__global__ __launch_bounds__(256, X3 ? 2 : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
+__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
     constexpr int TT = 32 * MT * WT;
@@ -390,6 +390,8 @@ hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
         if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
         return vlaunch<4, 2, 1, 4, 32>(p, stream);
     }
+    if (p.xf && p.small_tiles && co % 128 == 0 && ci % 128 == 0) return vlaunch_x<2, 1, 1, 4, 128, true>(p, stream);
+    if (p.xf && p.small_tiles && co % 64 == 0 && co % 128 && ci % 64 == 0) return vlaunch_x<2, 1, 2, 2, 64, true>(p, stream);
     if (co % 128 == 0) {
         if (ci % 128 == 0) return vlaunch<4, 1, 1, 4, 128>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 1, 1, 4, 64>(p, stream);
