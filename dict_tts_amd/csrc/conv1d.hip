@@ -253,7 +253,11 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 template <int ENGINE, int CK>
 static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStream_t stream) {
     if constexpr (ENGINE == ENG_F32) {
-        if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);  // 32 t x 256 co
+        // short sequences (the T_w ~ 27 encoder, B = 1): latency-bound by the serial fp32 MFMA chain of one wave (64 cycles per
+        // 32x32x2 MFMA); one co-tile per wave halves that chain at twice the workgroups (bit-identical: the order over K is unchanged)
+        // (gated layers keep two co-tiles per wave: the tanh tile and its sigmoid partner meet in the epilogue)
+        if (p.T_out <= 64 && !p.gate_H) return launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);  // 32 t x 128 co
+        if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);                 // 32 t x 256 co
         return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                      // 128 t x 64 co
     } else {
         if (L.C_out_pad <= 32) return launch_cfg<ENGINE, 2, 1, 4, 1, CK>(p, stream);   // 256 t x 32 co
