@@ -40,7 +40,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     constexpr int PK = 7, PH = (PK - 1) / 2;
     const int TTo = p.wav ? TT - 2 * PH : TT;
     const int t0 = blockIdx.x * TTo - (p.wav ? PH : 0);
-    const int len = p.lens ? p.lens[b] : p.T;
+    // (readfirstlane: hipcc loads lens[b] with a vector load — the kernel also stores through other pointers, so no scalar load —
+    // and a length in a VGPR would put every buffer resource below in VGPRs: a waterfall loop around each buffer access)
+    const int len = __builtin_amdgcn_readfirstlane(p.lens ? p.lens[b] : p.T);
     if (t0 + (p.wav ? PH : 0) >= len) return;
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;

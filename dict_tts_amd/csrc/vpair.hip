@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = TT - 2 * h2;             // valid output rows per workgroup
     const int t0 = blockIdx.x * TTe;
-    const int len = p.lens ? p.lens[b] : p.T;
+    // (readfirstlane: hipcc loads lens[b] with a vector load — the kernel also stores through other pointers, so no scalar load —
+    // and a length in a VGPR would put every buffer resource below in VGPRs: a waterfall loop around each buffer access)
+    const int len = __builtin_amdgcn_readfirstlane(p.lens ? p.lens[b] : p.T);
     if (t0 >= len) return;
     const long long brow = (long long)b * p.T;
     const int S = DTTS_DBG(p, 1) ? 0 : p.K * NKG;
