@@ -54,6 +54,26 @@ __device__ __forceinline__ float lrelu_op(float a, float slope) {
     if constexpr (EL == EL_F16) return __builtin_amdgcn_fmed3f(a, a * slope, 65504.f);
     else return lrelu(a, slope);
 }
+// four consecutive channels -> two dwords of 16-bit leaky_relu(v, slope): the slope products as two packed fp32 multiplies
+// (v_pk_mul_f32), the max / saturation per value, two packed converts — 8 VALU instructions for 4 values, same arithmetic as
+// pack2<EL>(lrelu_op<EL>(.), .) value by value (10)
+template <int EL>
+__device__ __forceinline__ uint2 act4(const f32x4& v, float slope) {
+    const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2_t ta = a * slope, tb = b * slope;
+    if constexpr (EL == EL_F16) {
+        return make_uint2(pack2<EL>(__builtin_amdgcn_fmed3f(a[0], ta[0], 65504.f), __builtin_amdgcn_fmed3f(a[1], ta[1], 65504.f)),
+                          pack2<EL>(__builtin_amdgcn_fmed3f(b[0], tb[0], 65504.f), __builtin_amdgcn_fmed3f(b[1], tb[1], 65504.f)));
+    } else {
+        float r0, r1, r2, r3;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(a[0]), "v"(ta[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(a[1]), "v"(ta[1]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r2) : "v"(b[0]), "v"(tb[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r3) : "v"(b[1]), "v"(tb[1]));
+        return make_uint2(pack2<EL>(r0, r1), pack2<EL>(r2, r3));
+    }
+}
+
 template <int EL>
 __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
     if constexpr (EL == EL_F16)

@@ -116,8 +116,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    uint2 pk = make_uint2(pack2<EL>(lrelu_op<EL>(v[m][n][4 * q], 0.1f), lrelu_op<EL>(v[m][n][4 * q + 1], 0.1f)),
-                                          pack2<EL>(lrelu_op<EL>(v[m][n][4 * q + 2], 0.1f), lrelu_op<EL>(v[m][n][4 * q + 3], 0.1f)));
+                    uint2 pk = act4<EL>(f32x4{v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]}, 0.1f);
                     if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }

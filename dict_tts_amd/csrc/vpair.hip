@@ -68,8 +68,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             for (int u = 0; u < U; ++u) {
                 if (kb + u >= nk) continue;
                 const f32x4 f = __builtin_bit_cast(f32x4, v[u]);
-                *(uint2*)(lrow + (kb + u) * (RSTEP * PITCH)) =
-                    make_uint2(pack2<EL>(lrelu_op<EL>(f[0], 0.1f), lrelu_op<EL>(f[1], 0.1f)), pack2<EL>(lrelu_op<EL>(f[2], 0.1f), lrelu_op<EL>(f[3], 0.1f)));
+                *(uint2*)(lrow + (kb + u) * (RSTEP * PITCH)) = act4<EL>(f, 0.1f);
             }
         }
     }
@@ -108,8 +107,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint2 pk = make_uint2(pack2<EL>(lrelu_op<EL>(acc[m][n][4 * q], 0.1f), lrelu_op<EL>(acc[m][n][4 * q + 1], 0.1f)),
-                                      pack2<EL>(lrelu_op<EL>(acc[m][n][4 * q + 2], 0.1f), lrelu_op<EL>(acc[m][n][4 * q + 3], 0.1f)));
+                uint2 pk = act4<EL>(f32x4{acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]}, 0.1f);
                 if (!inb) pk = make_uint2(0, 0);
                 *(uint2*)(smem + r * PITCH + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
             }
