@@ -3,7 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "voc_el.h"
-#include "voc_el.h"
 
 namespace dtts {
 
@@ -26,6 +25,7 @@ struct RBlockParams {
     const float* post_w;   // conv_post weight as [7 taps][C] fp32
     const float* post_b;   // [1]
     int el;                // 16-bit operand type: EL_BF16 (rb_common.h) or EL_F16; the packed weights are in that type
+    int pre_off;           // (set by the launcher) byte offset of the tile-count table in dynamic LDS
     int dbg;               // -DDTTS_ABLATE builds only; tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };
 
