@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "voc_el.h"
-#include "voc_el.h"
 
 namespace dtts {
 

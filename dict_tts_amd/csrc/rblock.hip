@@ -10,7 +10,7 @@
 //   * the tile carries a halo of 6*(k-1) rows per side (sum of the six receptive half-widths) that is recomputed;
 //     rows outside the utterance are forced to zero after every activation = the reference's zero padding.
 // HBM traffic per ResBlock drops from ~9 passes to: read x once, read-modify-write the stage accumulator once.
-// PS = 1 (the wide stages): persistent workgroups walk the batch's valid tiles, the next tile's x is fetched straight into the
+// PS = 1 (all but C = 32): persistent workgroups walk the batch's valid tiles, the next tile's x is fetched straight into the
 // residual registers (accumulator layout, no LDS transposition) slab by slab as the epilogue releases them.
 #include "rblock.h"
 #include "rb_common.h"
@@ -32,8 +32,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     char* act = smem;
     char* stage = smem + (size_t)(W + 2 * RB_GUARD) * PITCH;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wt = wave % WT, wc = wave / WT;
+    // per-thread coordinates; PS refreshes them through an opaque move at every tile (see the tile loop)
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wt = wave % WT, wc = wave / WT;
     const int H = 6 * (p.K - 1);
     const int TT = W - 2 * H;
     // fused conv_post (p.wav): the tile's TT valid rows give TT - (PK - 1) output samples, so tiles step by that and start
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     constexpr int RPP = THREADS / F4;              // rows one cooperative access of the workgroup covers (32 at C <= 64, 16 at C >= 128)
     constexpr int PER = SROWS / RPP;               // accesses per staging pass of SROWS = 32 rows per time-wave
     static_assert(THREADS % F4 == 0 && SROWS % RPP == 0 && RPP <= 32, "row-coalesced staging");
-    const int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, RPP)
+    int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, RPP)
     // staged row s = r0 + RPP * u of pass m <-> tile row: 32-row slab m of time-wave s / 32
     auto tile_row = [&](int m, int u) { const int sr = r0 + RPP * u; return ((sr >> 5) * MT + m) * 32 + (sr & 31); };
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
         for (int m = 0; m < MT; ++m) load_x(xr[m], m, b, t0 - H, len);
     } else {
-        // one tile per workgroup (C <= 64): coalesced whole-row loads, transposed into accumulator layout through the staging buffer
+        // one tile per workgroup (C = 32): coalesced whole-row loads, transposed into accumulator layout through the staging buffer
         // (the 32 B per row and instruction of the direct form cost 3 % at C = 32).  All MT*PER 16 B loads of a thread are issued
         // before the first LDS round trip: one exposed HBM latency per tile.
         const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long long)b * p.T * C), 0, len * C * 4, 0x00020000);
@@ -150,13 +151,22 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         }
     }
 
-    const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const int kg_stride = (C / 32) * 64;
     const int S = DTTS_DBG(p, 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
-    const size_t wlane = (size_t)(wc * NT) * 64 + lane;
 
 #pragma unroll 1
     for (;;) {
+    if constexpr (PS) {
+        // the thread index passes through an opaque move every tile: everything derived from it is recomputed per tile (a few VALU
+        // instructions) instead of being hoisted out of the tile loop by hipcc and spilled to scratch for lack of registers
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        wt = wave % WT, wc = wave / WT;
+        c4 = tid % F4, r0 = tid / F4;
+    }
+    const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+    const size_t wlane = (size_t)(wc * NT) * 64 + lane;
     t0 = __builtin_amdgcn_readfirstlane(t0);
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;
@@ -412,12 +422,12 @@ int rblock_padded_taps(int C, int K) {
     return kp;
 }
 
-// The wide stages run as persistent workgroups (-5 % at C = 128, -17 % at C = 256, same box); at C <= 64 the statically assigned tiles
-// lose what the hidden loads gain (C = 64 equal, C = 32 +10 %), so those keep one tile per workgroup.
+// Persistent workgroups everywhere but at C = 32 (same box: C = 64 -5 %, C = 128 -5 %, C = 256 -17 %; C = 32, two 4-wave workgroups
+// per CU, +1 %: that one keeps one tile per workgroup).
 template <int EL>
 static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream) {
     if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1, EL, 0>(p, stream);      // 512-row tile, 4 waves over time
-    if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 0>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
+    if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
     if (C == 128) return rb_launch_cfg<128, 4, 1, 2, 4, EL, 1>(p, stream);    // 256-row tile, 8 waves (2 time x 4 channel)
     if (C == 256) return rb_launch_cfg<256, 4, 1, 1, 8, EL, 1>(p, stream);    // 128-row tile, 8 waves over channels
     return hipErrorInvalidValue;

@@ -3,7 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "voc_el.h"
-#include "voc_el.h"
 
 namespace dtts {
 
@@ -21,6 +20,7 @@ struct VPairParams {
     int drop_y;           // mode 3 with ya: do not write the fp32 result (nothing reads it after the stage)
     float div, slope;
     int el;               // 16-bit operand type of both convolutions: EL_BF16 (rb_common.h) or EL_F16; w1 / w2 are packed in that type
+    int pre_off;          // (set by the launcher) byte offset of the tile table in dynamic LDS
     int dbg;              // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
 };
 

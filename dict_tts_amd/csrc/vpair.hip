@@ -22,22 +22,57 @@ namespace dtts {
 // C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
 template <int C, int TT, int EL>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
+    constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 4, NT = C / 128, MH = TT / 128, MTT = MT * MH;
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
-    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
-    const int b = blockIdx.y;
+    const int tid0 = threadIdx.x;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
-    const int TTe = TT - 2 * h2;             // valid output rows per workgroup
-    const int t0 = blockIdx.x * TTe;
-    // (readfirstlane: hipcc loads lens[b] with a vector load — the kernel also stores through other pointers, so no scalar load —
-    // and a length in a VGPR would put every buffer resource below in VGPRs: a waterfall loop around each buffer access)
-    const int len = __builtin_amdgcn_readfirstlane(p.lens ? p.lens[b] : p.T);
-    if (t0 >= len) return;
-    const long long brow = (long long)b * p.T;
+    const int TTe = TT - 2 * h2;             // valid output rows per tile
     const int S = DTTS_DBG(p, 1) ? 0 : p.K * NKG;
+    // ---- persistent workgroups (as in rblock.hip): the valid tiles of the batch, ceil(len_b / TTe) per utterance, are numbered
+    // through and workgroup w takes tiles w, w + G, ...; the table of the per-utterance tile counts' prefix sums and the lengths
+    // live in LDS behind the tile.  A tile's stores drain while the next tile is staged, and no workgroup is launched per tile.
+    int* pre = (int*)(smem + p.pre_off);
+    int total = 1, b = 0;
+    if constexpr (PS) {
+        for (int i = tid0; i < p.B; i += 256) {
+            const int l = p.lens ? p.lens[i] : p.T;
+            pre[p.B + 1 + i] = (l + TTe - 1) / TTe;
+            pre[2 * p.B + 1 + i] = l;
+        }
+        __syncthreads();
+        for (int i = tid0; i <= p.B; i += 256) {
+            int a = 0;
+            for (int u = 0; u < i; ++u) a += pre[p.B + 1 + u];
+            pre[i] = a;
+        }
+        __syncthreads();
+        total = pre[p.B];
+    }
+#pragma unroll 1
+    for (int j = PS ? blockIdx.x : 0; j < total; j += gridDim.x) {
+    // (the thread index passes through an opaque move every tile: everything derived from it is then recomputed per tile — a few
+    // VALU instructions — instead of being hoisted out of the tile loop by hipcc and spilled to scratch for lack of registers)
+    int tid = tid0;
+    if constexpr (PS) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int len, t0;
+    if constexpr (PS) {
+        while (pre[b + 1] <= j) ++b;             // the utterance index only moves forward
+        b = __builtin_amdgcn_readfirstlane(b);
+        // (readfirstlane: a length in a VGPR would put every buffer resource below in VGPRs: a waterfall loop around each buffer access)
+        len = __builtin_amdgcn_readfirstlane(pre[2 * p.B + 1 + b]);
+        t0 = __builtin_amdgcn_readfirstlane((j - pre[b]) * TTe);
+    } else {   // one tile per workgroup: grid (tiles, utterances)
+        b = blockIdx.y;
+        len = __builtin_amdgcn_readfirstlane(p.lens ? p.lens[b] : p.T);
+        t0 = blockIdx.x * TTe;
+        if (t0 >= len) return;
+    }
+    const long long brow = (long long)b * p.T;
 
     uint4 ring[4][NT];
     const size_t wlane = (size_t)wc * NT * 64 + lane;   // the wave's first co-tile
@@ -125,7 +160,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 
     if (DTTS_DBG(p, 2)) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
-        return;
+        if constexpr (!PS) break;
+        continue;
     }
     // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
     // Buffer loads / stores again: rows >= len are dropped by the range check, the garbage rows o >= TTe of the last
@@ -183,6 +219,9 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             }
         }
     }
+    if constexpr (!PS) break;
+    __syncthreads();   // the epilogue's staging rows alias the tile the next iteration stages into
+    }   // (tiles of this workgroup)
 }
 
 bool vpair_supported(int C, int K, int dil) {
@@ -194,13 +233,19 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = TT - 2 * h2;
-    // staged rows + one spare tap for the activation prefetch; the xt phase needs TT + (K-1) + 1 rows, the epilogue 32 fp32 rows
-    constexpr int RSTEP = 256 / (CC / 4);                        // the staging loop rounds the row count up to its step
-    size_t rows = (size_t)TT + 2 * h1 + p.dil + 1 + RSTEP;
+    // staged rows, rounded up to the staging loop's step, or one spare tap for c1's activation prefetch, whichever reaches further;
+    // the xt phase needs TT + (K-1) + 1 rows, the epilogue 32 fp32 rows
+    constexpr int RSTEP = 256 / (CC / 4);
+    size_t rows = (size_t)TT + 2 * h1 + std::max(p.dil + 1, RSTEP);
     if (rows < (size_t)TT + p.K + 1) rows = TT + p.K + 1;
     size_t lds = rows * PITCH;
     const size_t ep = (size_t)32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
+    VPairParams q = p;
+    q.pre_off = (int)lds;                          // tile table: prefix sums [B + 1], counts [B], lengths [B]
+    constexpr bool PS = !(CC == 128 && TT == 128);
+    if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = vpair_kernel<CC, TT, EL>;
     static bool configured = false;
     if (!configured) {
@@ -208,8 +253,23 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    dim3 grid((p.T + TTe - 1) / TTe, p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    if (!PS) {
+        hipLaunchKernelGGL(kern, dim3((p.T + TTe - 1) / TTe, p.B), dim3(256), lds, stream, q);
+        return hipGetLastError();
+    }
+    // persistent workgroups: as many as are resident at once (LDS, the kernel's register bound), never more than there can be tiles
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount;
+    }
+    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), (CC == 128 && TT == 128) ? 3 : 2));
+    const long long max_tiles = (long long)p.B * ((p.T + TTe - 1) / TTe);
+    const int grid = (int)std::min<long long>((long long)cus * per_cu, max_tiles);
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 
@@ -217,8 +277,8 @@ template <int EL>
 static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t stream) {
     if (C == 256) return vpair_launch_tt<256, 128, EL>(p, stream);
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
-    const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + p.dil + 1 + 8;
-    const bool big = rows256 * (128 * 2 + 16) * 2 <= 160 * 1024;
+    const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
+    const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
     return big ? vpair_launch_tt<128, 256, EL>(p, stream) : vpair_launch_tt<128, 128, EL>(p, stream);
 }
 
