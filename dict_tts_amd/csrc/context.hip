@@ -970,6 +970,14 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     vp.slope = last_stage ? 0.01f : 0.1f;
                     vp.el = el;
                     vp.dbg = g_ablate >> 8;
+#ifdef DTTS_ABLATE
+                    if (getenv("DTTS_VP_STATS")) {   // per-phase cycles of wave 0 (staging, c1, rewrite, c2, epilogue incl. store acks), printed per launch
+                        static unsigned long long* dstats = nullptr;
+                        if (!dstats) hipMalloc((void**)&dstats, 64);
+                        hipMemsetAsync(dstats, 0, 64, s);
+                        vp.stats = dstats;
+                    }
+#endif
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;
@@ -982,6 +990,16 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     xin = vp.y;
                     Timed tm(h, TV, s);
                     LAUNCH(vpair_launch(vp, ch, s));
+#ifdef DTTS_ABLATE
+                    if (vp.stats) {
+                        unsigned long long hs[8];
+                        hipStreamSynchronize(s);
+                        hipMemcpy(hs, vp.stats, 64, hipMemcpyDeviceToHost);
+                        const double n = hs[5] ? (double)hs[5] : 1.0;
+                        fprintf(stderr, "vpair C=%d K=%d d=%d mode=%d tiles=%llu  cycles/tile: stage %.0f c1 %.0f rewrite %.0f c2 %.0f epilogue %.0f\n", ch, vp.K, vp.dil,
+                                vp.mode, hs[5], hs[0] / n, hs[1] / n, hs[2] / n, hs[3] / n, hs[4] / n);
+                    }
+#endif
                 }
                 continue;
             }

@@ -21,6 +21,7 @@ struct VPairParams {
     float div, slope;
     int el;               // 16-bit operand type of both convolutions: EL_BF16 (rb_common.h) or EL_F16; w1 / w2 are packed in that type
     int pre_off;          // (set by the launcher) byte offset of the tile table in dynamic LDS
+    unsigned long long* stats;   // -DDTTS_ABLATE builds only: per-phase cycle sums of wave 0 (see vpair.hip), or null
     int dbg;              // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG >> 8): 1 skip contractions, 2 skip epilogue, 4 skip staging, 8 skip xt write
 };
 

@@ -74,6 +74,13 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     }
     const long long brow = (long long)b * p.T;
 
+#ifdef DTTS_ABLATE
+    unsigned long long tq[6];
+#define VP_STAMP(i) tq[i] = __builtin_amdgcn_s_memtime()
+#else
+#define VP_STAMP(i)
+#endif
+    VP_STAMP(0);
     uint4 ring[4][NT];
     const size_t wlane = (size_t)wc * NT * 64 + lane;   // the wave's first co-tile
     rb_preload<NT>(ring, p.w1 + wlane, NCT * 64);   // c1's first weights fly while the tile is staged
@@ -90,7 +97,10 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
     if (!DTTS_DBG(p, 4)) {
-        constexpr int U = 12;                       // independent loads in flight per thread and batch
+#ifndef VP_U
+#define VP_U 12
+#endif
+        constexpr int U = VP_U;                     // independent loads in flight per thread and batch
         const int nk = (arows + RSTEP - 1) / RSTEP;
         const int voff0 = ((a0 + r0) * C + c4 * 4) * 4;
         char* lrow = smem + r0 * PITCH + c4 * 8;
@@ -114,6 +124,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 #pragma unroll
         for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b1 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     __syncthreads();
+    VP_STAMP(1);
 
     // ---- c1: xt rows r = 0..127  <->  global t0 - h2 + r ; reads staged rows r + tap * d
     f32x16 acc[MTT][NT];
@@ -131,6 +142,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
     rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
+    VP_STAMP(2);
     __syncthreads();   // every wave is done reading the x tile
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
 #pragma unroll
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             }
     }
     __syncthreads();
+    VP_STAMP(3);
     // ---- c2: output rows o = 0..127 <-> global t0 + o (valid for o < TTe) ; reads xt rows o + tap
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 #pragma unroll
             for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
     rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
+    VP_STAMP(4);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
     if (DTTS_DBG(p, 2)) {
@@ -219,6 +233,16 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             }
         }
     }
+#ifdef DTTS_ABLATE
+    if (p.stats) {
+        asm volatile("s_waitcnt vmcnt(0)");   // the stores' acknowledgements are part of the epilogue's time here
+        VP_STAMP(5);
+        if (tid == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(p.stats + i, tq[i + 1] - tq[i]);
+            atomicAdd(p.stats + 5, 1ull);
+        }
+    }
+#endif
     if constexpr (!PS) break;
     __syncthreads();   // the epilogue's staging rows alias the tile the next iteration stages into
     }   // (tiles of this workgroup)
