@@ -1,4 +1,6 @@
 #!/bin/bash
+# phase ablation of the fused vocoder kernels (run on the GPU box): needs dict_tts_amd/libdicttts_abl.so = a build with -DDTTS_ABLATE;
+#   tools/abl_voc.sh <DTTS_VCONV_DBG values...>   (rblock bits << 4, vpair bits << 8: 1 contractions, 2 epilogue, 4 x load, 8 rewrites)
 cp dict_tts_amd/libdicttts_hip.so /tmp/rel.so
 cp dict_tts_amd/libdicttts_abl.so dict_tts_amd/libdicttts_hip.so
 for v in $@; do
