@@ -24,7 +24,7 @@ template <int C, int TT, int EL>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = C / 128, MH = TT / 128, MTT = MT * MH;
+    constexpr int MT = TT == 192 ? 3 : 4, NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
@@ -135,12 +135,16 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
+    auto load_b2 = [&]() {
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b2 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
+            for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b2 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
+    };
+    if (NT == 1) load_b2();   // lands while c1 runs; at C = 256 its 32 registers do not fit beside c1's (spills): fetched after c1 there
     const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
     rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
+    if (NT != 1) load_b2();
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
     VP_STAMP(2);
     __syncthreads();   // every wave is done reading the x tile
@@ -303,7 +307,9 @@ static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t strea
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
     const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
-    return big ? vpair_launch_tt<128, 256, EL>(p, stream) : vpair_launch_tt<128, 128, EL>(p, stream);
+    if (big) return vpair_launch_tt<128, 256, EL>(p, stream);
+    // k = 11 with dilation 5: 192-row tiles (two workgroups per CU, persistent) instead of 128-row ones (three, one tile each)
+    return vpair_launch_tt<128, 192, EL>(p, stream);
 }
 
 hipError_t vpair_launch(const VPairParams& p, int C, hipStream_t stream) {
