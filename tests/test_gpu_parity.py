@@ -217,6 +217,32 @@ def test_hifigan_ragged_batch_equals_per_utterance_oracle(voc, voc_x3, voc_bf16,
     assert float(full[0, 5 * 256:].abs().max()) == 0.0
 
 
+def test_hifigan_many_utterances_persistent_tiles(voc, oracle_voc_sd):
+    """the fused kernels' persistent workgroups walk the batch's valid tiles through a tile table (utterance -> tile count prefix sums):
+    70 utterances, lengths 0..61 incl. empty and one-frame ones, enough tiles that every workgroup takes several — each row of the
+    batched output is BIT-identical to the same utterance run alone (same tile origins), zero past its end, and within the waveform
+    gate of the oracle"""
+    from oracle import hifigan_ref as href
+    rng = np.random.RandomState(7)
+    lens = [0, 1, 61, 2, 33] + [int(v) for v in rng.randint(0, 62, size=65)]
+    B, Tm = len(lens), 64
+    mel = np.zeros((B, Tm, 80), np.float32)
+    for i, n in enumerate(lens):
+        if n:
+            mel[i, :n] = synth.random_mel(300 + i, n, f"many{i}")
+    full = voc.forward_batch(T(mel).cuda(), torch.tensor(lens, dtype=torch.int32)).cpu().numpy()
+    assert np.isfinite(full).all()
+    for i, n in enumerate(lens):
+        assert float(np.abs(full[i, n * 256:]).max(initial=0.0)) == 0.0
+        if n == 0:
+            continue
+        if i < 12 or n >= 60:
+            alone = voc.spec2wav(mel[i, :n])
+            assert np.array_equal(alone, full[i, :n * 256]), i
+        if i in (1, 2, 4, 20):
+            wave_gate(full[i, :n * 256], href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel[i, :n]).numpy())
+
+
 def test_hifigan_linearity_free_properties_long(voc):
     voc_bf16 = voc
     """size-independent properties at a realistic length (400 frames): determinism, finite output in (-1, 1),
