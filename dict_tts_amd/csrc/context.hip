@@ -20,6 +20,7 @@
 #include "vconv.h"
 #include "rblock.h"
 #include "vpair.h"
+#include "flowstack.h"
 
 using namespace dtts;
 
@@ -121,6 +122,8 @@ struct dtts_ctx {
     float *dur_w = nullptr, *dur_bias = nullptr;
     PackedConv g_pre, dec_pre, dec_out;
     std::vector<Flow> flows;  // in execution (reversed) order
+    float* fs_w = nullptr;    // packed weights of the fused prior-flow kernel (flowstack.hip), or null = launch by launch
+    PackedConv fs_cond;       // cond_layer of ALL blocks as one 1x1 convolution (execution order)
     WNet dec_wn;
     // ---- vocoder
     PackedConv conv_pre, conv_post;
@@ -469,6 +472,10 @@ int build_acoustic(dtts_ctx* h) {
     const int half = c.latent_size / 2;
     h->flows.clear();
     int parity = 0;
+    // one fused kernel for the whole prior flow where the configuration allows (DTTS_TUNE bit 8: launch by launch again)
+    bool fuse_flows = flowstack_supported(c.prior_glow_hidden, c.glow_kernel_size, c.prior_glow_n_layers, c.prior_glow_n_blocks, c.latent_size) &&
+                      !(h->tune & 256);
+    std::vector<float> fs_host, fs_cond_w, fs_cond_b;
     for (int f = c.prior_glow_n_blocks - 1; ok && f >= 0; --f) {
         // reversed(flows): Flip, then the coupling layer (glow_modules.py:157-163).  The flip is not executed:
         // it is tracked as a parity and folded into the channel order of pre / post.
@@ -493,8 +500,50 @@ int build_acoustic(dtts_ctx* h) {
                              [=](int co, int ci, int) { return -ppost[(size_t)(rev ? half - 1 - co : co) * Hf + ci]; }, nb, 1, 1, 0);
         ok = ok && build_wn(h, need, fl.wn, p + ".enc", Hf, c.glow_kernel_size, c.prior_glow_n_layers);
         h->flows.push_back(fl);
+        if (ok && fuse_flows) {   // the same block for the fused kernel (flowstack.hip): logical weights with the flip folded in as above
+            FlowStackHostWeights fw;
+            fw.pre.resize((size_t)Hf * half);
+            for (int co = 0; co < Hf; ++co)
+                for (int ci = 0; ci < half; ++ci) fw.pre[(size_t)co * half + ci] = ppre[(size_t)co * half + (rev ? half - 1 - ci : ci)];
+            fw.bpre = bpre;
+            fw.post.resize((size_t)half * Hf);
+            for (int q = 0; q < half; ++q)
+                for (int ci = 0; ci < Hf; ++ci) fw.post[(size_t)q * Hf + ci] = -ppost[(size_t)(rev ? half - 1 - q : q) * Hf + ci];
+            fw.bpost = nb;
+            for (int l = 0; ok && l < c.prior_glow_n_layers; ++l) {
+                const std::string bi = p + ".enc.in_layers." + std::to_string(l), br = p + ".enc.res_skip_layers." + std::to_string(l);
+                const HostTensor *wi = folded_weight(h, need, bi), *wr = folded_weight(h, need, br);
+                std::vector<float> b1 = bias_of(need, bi), b2 = bias_of(need, br);
+                const size_t n_rs = (size_t)(l == c.prior_glow_n_layers - 1 ? Hf : 2 * Hf);
+                if (!wi || !wr || wi->f.size() != (size_t)2 * Hf * Hf * c.glow_kernel_size || wr->f.size() != n_rs * Hf || b1.size() != (size_t)2 * Hf ||
+                    b2.size() != n_rs) {
+                    fuse_flows = false;   // an unexpected shape: the launch-by-launch path reports it
+                    break;
+                }
+                fw.in.push_back(wi->f);
+                fw.bin.push_back(b1);
+                fw.rs.push_back(wr->f);
+                fw.brs.push_back(b2);
+            }
+            const HostTensor* wc = fuse_flows ? folded_weight(h, need, p + ".enc.cond_layer") : nullptr;
+            std::vector<float> bc = fuse_flows ? bias_of(need, p + ".enc.cond_layer") : std::vector<float>();
+            const size_t n_c = (size_t)2 * Hf * c.prior_glow_n_layers;
+            if (fuse_flows && (!wc || wc->f.size() != n_c * c.hidden_size || bc.size() != n_c)) fuse_flows = false;
+            if (fuse_flows) {
+                flowstack_pack(fw, c.prior_glow_n_layers, fs_host);
+                fs_cond_w.insert(fs_cond_w.end(), wc->f.begin(), wc->f.end());
+                fs_cond_b.insert(fs_cond_b.end(), bc.begin(), bc.end());
+            }
+        }
     }
     if (ok && parity != 0) return fail(h, DTTS_E_INVAL, "odd number of flow blocks is not supported");
+    h->fs_w = nullptr;
+    if (ok && fuse_flows && !h->flows.empty()) {
+        h->fs_w = upload(h, fs_host);
+        const int n_c = (int)fs_cond_b.size(), Cg = c.hidden_size;
+        const float* pc = fs_cond_w.data();
+        ok = ok && h->fs_w && pack_conv(h, h->fs_cond, ENG_F32, n_c, Cg, 1, [=](int co, int ci, int) { return pc[(size_t)co * Cg + ci]; }, fs_cond_b, 1, 1, 0);
+    }
     ok = ok && pack_transposed(h, need, h->dec_pre, ENG_F32, m + "fvae.decoder.pre_net.0", 4, 0);
     // the decoder WaveNet carries 4.09 of the acoustic model's 4.69 MFLOP per frame: split-bf16 operands (three bf16 MFMAs
     // per product = 5.3x the fp32-MFMA rate, mel error ~3e-5 against the 1e-3 gate) unless the hidden width does not tile
@@ -1579,7 +1628,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     const size_t mrows = (size_t)B * T_mel, qrows = (size_t)B * T4;
     const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
     HIPCHK(h->a_dec.reserve(mrows * (size_t)(C + 1 + 2 + 2 * Hd * c.fvae_dec_n_layers + 3 * Hd + 8) * sizeof(float) +
-                            qrows * (size_t)(C + c.latent_size + 2 * Hf * c.prior_glow_n_layers + 3 * Hf + 8) * sizeof(float) +
+                            qrows * (size_t)(C + 2 * c.latent_size + 2 * Hf * c.prior_glow_n_layers * (1 + c.prior_glow_n_blocks) + 3 * Hf + 16) * sizeof(float) +
                             (size_t)B * T_w * 2 * Hd * c.fvae_dec_n_layers * sizeof(float) + (64 << 10)));
     h->m2w = h->a_dec.alloc<int64_t>(mrows);
     h->x_mask = h->a_dec.alloc<float>(mrows);
@@ -1702,6 +1751,32 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
         LAUNCH(normal_fill_launch(z, (long long)qrows * Z, ++h->noise_counter, s));   // z_p ~ N(0,1) (fvae_semantics.py:110-111)
     }
     // A9: prior flow, reverse
+    if (h->fs_w) {   // every block in one kernel (flowstack.hip); the conditioning of all blocks by one convolution
+        const int n_c = h->fs_cond.C_out;
+        float* cond_all = A.alloc<float>(qrows * n_c);
+        float* z2 = A.alloc<float>(qrows * Z);
+        if (!cond_all || !z2) return fail(h, DTTS_E_NOMEM, "decoder workspace");
+        p = base_params(gs, C, B, T4, T4, cond_all, n_c);
+        LAUNCH(conv1d_launch(h->fs_cond, p, s));
+        FlowStackParams fp;
+        memset(&fp, 0, sizeof fp);
+        fp.z_in = z;
+        fp.z_out = z2;
+        fp.cond = cond_all;
+        fp.ld_cond = n_c;
+        fp.w = h->fs_w;
+        fp.B = B;
+        fp.T4 = T4;
+        fp.Z = Z;
+        fp.n_flows = (int)h->flows.size();
+        fp.layers = c.prior_glow_n_layers;
+        for (size_t i = 0; i < h->flows.size(); ++i) {
+            fp.in_coff[i] = h->flows[i].in_coff;
+            fp.out_coff[i] = h->flows[i].out_coff;
+        }
+        LAUNCH(flowstack_launch(fp, s));
+        z = z2;
+    } else
     for (const Flow& fl : h->flows) {
         p = base_params(z, Z, B, T4, T4, fh, Hf);
         p.x_coff = fl.in_coff;

@@ -1,0 +1,324 @@
+// The FVAE prior flow in reverse (z_p -> z_q; modules/dict_tts/fvae_semantics.py:112-113, modules/commons/glow_modules /
+// ResidualCouplingBlock.forward(reverse=True): for each block, last to first: Flip, then the mean-only coupling layer
+//     h = pre(x0) ; out = WN(h, g) ; m = post(out) ; x1 = x1 - m
+// with WN (modules/commons/wavenet.py:54-78) = n_layers x [ in_layer (k = 3) + cond -> tanh * sigmoid -> res_skip (1x1) ]) as ONE
+// kernel in exact fp32.  Launch by launch that is 11 kernels per block — pre, cond, 4 x (in, res_skip), post — each a few GFLOP on
+// T_mel/4 rows x 64 channels, i.e. 44 latency-bound launches per batch; here a workgroup takes a chunk of 128 rows (of which
+// 128 - 2 * n_blocks * n_layers are valid: every k = 3 convolution eats one halo row per side) through ALL blocks:
+//   * z (16 channels), the WaveNet state h (64) and the gated activations (64) live in LDS as fp32 rows; wave w owns rows
+//     32w .. 32w+31 for every output channel, so tanh / sigmoid partners, the 1x1 res_skip convolution's input and the skip
+//     accumulator are all wave-local (registers / own LDS rows); only the k = 3 in_layer reads neighbouring waves' rows: two
+//     barriers per layer;
+//   * contractions on v_mfma_f32_32x32x2_f32 (D[co][t]: A = weights, B = LDS rows); the K order is chosen so that a lane's four
+//     consecutive steps read four consecutive channels: one ds_read_b128 of the state and one 16 B weight fragment per co-tile
+//     feed 16 MFMAs.  Weights stream from L2 in fragment order (context.hip: flowstack_pack);
+//   * the conditioning (cond_layer(g) of all blocks: one [B*T4, 256] x [256, 2048] convolution, launched once before) enters as
+//     the accumulators' initial value together with the bias;
+//   * pre (8 -> 64) and post (64 -> 8) on the VALU; rows outside [0, T4) are forced to zero after every update = the
+//     convolutions' zero padding (the reference runs the flow with x_mask = 1 over the padded batch).
+#include "flowstack.h"
+
+#include <algorithm>
+
+namespace dtts {
+
+typedef __attribute__((ext_vector_type(16))) float fs16;
+typedef __attribute__((ext_vector_type(4))) float fs4;
+
+namespace {
+constexpr int W = 128;                 // rows per chunk (4 waves x 32)
+constexpr int HP = FS_H + 4;           // LDS row pitch of h / acts (floats): 272 B rows, conflict-free ds_read_b128 over 16 rows
+constexpr int ZP = 16;                 // z row (floats)
+}
+
+__global__ __launch_bounds__(256, 1) void flowstack_kernel(const FlowStackParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* zt = (float*)smem_raw;                       // [W][ZP]
+    float* hb = zt + W * ZP;                            // [W + 2][HP], row 0 and W + 1 are zero guards
+    float* ab = hb + (W + 2) * HP;                      // [W][HP]
+    float* wp = ab + W * HP;                            // pre / post weights of the current block: FS_PRE + FS_POST floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int halo = p.n_flows * p.layers;
+    const int RC = W - 2 * halo;
+    const int b = blockIdx.y;
+    const int t_base = blockIdx.x * RC - halo;
+    const int row_l = 32 * wave + (lane & 31);
+    const int t = t_base + row_l;
+    const bool inb = t >= 0 && t < p.T4;
+    const long long grow = (long long)b * p.T4 + t;    // global row (valid when inb)
+
+    // ---- z tile (zeros outside the sequence), guard rows
+    for (int i = tid; i < W * ZP / 4; i += 256) {
+        const int r = i / (ZP / 4), c = i % (ZP / 4);
+        const int tt = t_base + r;
+        fs4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tt >= 0 && tt < p.T4 && c * 4 < p.Z) v = *(const fs4*)(p.z_in + ((long long)b * p.T4 + tt) * p.Z + c * 4);
+        *(fs4*)(zt + r * ZP + c * 4) = v;
+    }
+    for (int i = tid; i < 2 * HP; i += 256) hb[(i < HP ? 0 : (W + 1) * HP - HP) + i] = 0.f;
+    float* hrow = hb + (1 + row_l) * HP;               // this lane's row of the state
+    float* arow = ab + row_l * HP;
+
+    // this lane's conditioning of layer g = block * layers + layer (its row, its 64 of the 128 gate channels), fetched one layer ahead
+    fs4 cnd[4][4];
+    auto load_cond = [&](int g) {   // (+ the in_layer's bias: both are the accumulators' initial value)
+        if (g >= p.n_flows * p.layers) return;
+        const float* bin = p.w + (size_t)(g / p.layers) * fs_flow_floats(p.layers) + FS_PRE + (size_t)(g % p.layers) * FS_LAYER + FS_IN_FRAGS + 4 * half;
+        const float* cr = p.cond + grow * p.ld_cond + (size_t)g * 2 * FS_H + 4 * half;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cnd[n][q] = *(const fs4*)(bin + 32 * n + 8 * q);
+                if (inb) cnd[n][q] += *(const fs4*)(cr + 32 * n + 8 * q);
+            }
+    };
+    load_cond(0);
+    const size_t flow_floats = fs_flow_floats(p.layers);
+#pragma unroll 1
+    for (int f = 0; f < p.n_flows; ++f) {
+        const float* wf = p.w + (size_t)f * flow_floats;
+        __syncthreads();   // the previous block's readers of wp / hb are done (and the z tile / guards are in place)
+        for (int i = tid; i < (int)FS_PRE; i += 256) wp[i] = wf[i];
+        for (int i = tid; i < (int)FS_POST; i += 256) wp[FS_PRE + i] = wf[FS_PRE + (size_t)p.layers * FS_LAYER + i];
+        __syncthreads();
+        // ---- h = pre(x0): this lane's 32 channels (co-tiles 0, 1) of its row
+        {
+            const fs4 xa = *(const fs4*)(zt + row_l * ZP + p.in_coff[f]), xb = *(const fs4*)(zt + row_l * ZP + p.in_coff[f] + 4);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fs4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 32 * n + 8 * q + 4 * half + e;
+                        const fs4 wa = *(const fs4*)(wp + c * FS_HALF), wb = *(const fs4*)(wp + c * FS_HALF + 4);
+                        float a = wp[FS_H * FS_HALF + c];
+                        a += wa[0] * xa[0]; a += wa[1] * xa[1]; a += wa[2] * xa[2]; a += wa[3] * xa[3];
+                        a += wb[0] * xb[0]; a += wb[1] * xb[1]; a += wb[2] * xb[2]; a += wb[3] * xb[3];
+                        hv[e] = inb ? a : 0.f;
+                    }
+                    *(fs4*)(hrow + 32 * n + 8 * q + 4 * half) = hv;
+                }
+        }
+        fs16 skip[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) skip[n][i] = 0.f;
+        __syncthreads();
+
+#pragma unroll 1
+        for (int l = 0; l < p.layers; ++l) {
+            const float* wl = wf + FS_PRE + (size_t)l * FS_LAYER;
+            const fs4* in_frag = (const fs4*)wl + lane;
+            const fs4* rs_frag = (const fs4*)(wl + FS_IN_FRAGS + 2 * FS_H) + lane;
+            const float* brs = wl + FS_IN_FRAGS + 2 * FS_H + FS_RS_FRAGS;
+            const bool last = l == p.layers - 1;
+            // ---- x_in = in_layer(h) + bias + cond: the accumulators start at bias + cond
+            fs16 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const fs4 v = cnd[n][q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
+                }
+            {
+                // weight fragments run PFD steps ahead through a register ring (L2 latency under the MFMAs); the state row one step ahead
+                constexpr int NIT = FS_K * (FS_H / 8), PFD = 3;
+                fs4 a[PFD + 1][4];
+#pragma unroll
+                for (int s0 = 0; s0 < PFD; ++s0)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) a[s0][n] = in_frag[(s0 * 4 + n) * 64];
+                fs4 bv = *(const fs4*)(hrow - HP + 4 * half);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (it + PFD < NIT) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) a[(it + PFD) % (PFD + 1)][n] = in_frag[((it + PFD) * 4 + n) * 64];
+                    }
+                    fs4 bn = bv;
+                    if (it + 1 < NIT) {
+                        const int tap = (it + 1) / (FS_H / 8), j = (it + 1) % (FS_H / 8);
+                        bn = *(const fs4*)(hrow + (tap - 1) * HP + 4 * half + 8 * j);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it % (PFD + 1)][n][e], bv[e], acc[n], 0, 0, 0);
+                    bv = bn;
+                }
+            }
+            load_cond(f * p.layers + l + 1);   // the next layer's (or block's) conditioning travels during the gate and the 1x1 convolution
+            // ---- acts = tanh(x_in[:H]) * sigmoid(x_in[H:]) -> this lane's row of the activation tile
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fs4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // tanh(a) * sigmoid(g) = (1 - 2 / (e^{2a} + 1)) / (1 + e^{-g}), hardware exp2 / rcp (a few ulp; the launch-by-launch
+                        // path calls tanhf / expf): both forms saturate cleanly (e^{2a} = inf -> 1, 0 -> -1)
+                        const float ea = __expf(2.f * acc[n][4 * q + e]), eg = __expf(-acc[n + 2][4 * q + e]);
+                        v[e] = (1.f - 2.f * __frcp_rn(ea + 1.f)) * __frcp_rn(1.f + eg);
+                    }
+                    *(fs4*)(arow + 32 * n + 8 * q + 4 * half) = v;
+                }
+            // ---- res_skip(acts) (1x1: this wave's own rows), bias as the initial accumulators
+            const int nrs = last ? 2 : 4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fs4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n < nrs) v = *(const fs4*)(brs + 32 * n + 8 * q + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
+                }
+            {
+                constexpr int NIT = FS_H / 8, PFD = 3;
+                fs4 a[PFD + 1][4];
+#pragma unroll
+                for (int s0 = 0; s0 < PFD; ++s0)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) a[s0][n] = (n < nrs) ? rs_frag[(s0 * 4 + n) * 64] : fs4{0.f, 0.f, 0.f, 0.f};
+                fs4 bv = *(const fs4*)(arow + 4 * half);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (it + PFD < NIT) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) a[(it + PFD) % (PFD + 1)][n] = (n < nrs) ? rs_frag[((it + PFD) * 4 + n) * 64] : fs4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    fs4 bn = bv;
+                    if (it + 1 < NIT) bn = *(const fs4*)(arow + 8 * (it + 1) + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it % (PFD + 1)][0][e], bv[e], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it % (PFD + 1)][1][e], bv[e], acc[1], 0, 0, 0);
+                        if (!last) {
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it % (PFD + 1)][2][e], bv[e], acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it % (PFD + 1)][3][e], bv[e], acc[3], 0, 0, 0);
+                        }
+                    }
+                    bv = bn;
+                }
+            }
+            __syncthreads();   // every wave has read its neighbours' rows of h for this layer
+            if (!last) {
+                // h = h + res ; skip += skip part   (wavenet.py:71-75)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float* hp = hrow + 32 * n + 8 * q + 4 * half;
+                        fs4 v = *(const fs4*)hp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = inb ? v[e] + acc[n][4 * q + e] : 0.f;
+                        *(fs4*)hp = v;
+                    }
+                skip[0] += acc[2];
+                skip[1] += acc[3];
+            } else {
+                skip[0] += acc[0];
+                skip[1] += acc[1];
+            }
+            __syncthreads();   // h is updated
+        }
+        // ---- x1 = x1 - post(out): 8 outputs per row; this lane holds 32 of the 64 channels, its partner lane ^ 32 the others
+        {
+            const float* wq = wp + FS_PRE;             // Wpost'[8][64], bpost'[8]
+            float m[FS_HALF];
+#pragma unroll
+            for (int o = 0; o < FS_HALF; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const fs4 wv = *(const fs4*)(wq + o * FS_H + 32 * n + 8 * q + 4 * half);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a += wv[e] * skip[n][4 * q + e];
+                    }
+                m[o] = a + __shfl_xor(a, 32, 64);
+            }
+            if (half == 0) {
+                float* zp = zt + row_l * ZP + p.out_coff[f];
+#pragma unroll
+                for (int o = 0; o < FS_HALF; ++o) zp[o] += m[o] + wq[FS_HALF * FS_H + o];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the valid rows of the chunk leave
+    for (int i = tid; i < W * ZP / 4; i += 256) {
+        const int r = i / (ZP / 4), c = i % (ZP / 4);
+        const int tt = t_base + r;
+        if (r >= halo && r < W - halo && tt >= 0 && tt < p.T4 && c * 4 < p.Z)
+            *(fs4*)(p.z_out + ((long long)b * p.T4 + tt) * p.Z + c * 4) = *(const fs4*)(zt + r * ZP + c * 4);
+    }
+}
+
+bool flowstack_supported(int hidden, int kernel, int layers, int blocks, int latent) {
+    return hidden == FS_H && kernel == FS_K && latent == 2 * FS_HALF && layers >= 1 && layers <= FS_MAX_LAYERS && blocks >= 1 &&
+           blocks <= FS_MAX_FLOWS && 2 * blocks * layers <= W - 32;
+}
+
+void flowstack_pack(const FlowStackHostWeights& w, int layers, std::vector<float>& out) {
+    const size_t base = out.size();
+    out.resize(base + fs_flow_floats(layers), 0.f);
+    float* o = out.data() + base;
+    for (int c = 0; c < FS_H; ++c)
+        for (int i = 0; i < FS_HALF; ++i) o[c * FS_HALF + i] = w.pre[(size_t)c * FS_HALF + i];
+    for (int c = 0; c < FS_H; ++c) o[FS_H * FS_HALF + c] = w.bpre[c];
+    for (int l = 0; l < layers; ++l) {
+        float* wl = o + FS_PRE + (size_t)l * FS_LAYER;
+        const bool last = l == layers - 1;
+        // fragment(tap, j, n, lane)[e] = W[co = 32 n + (lane & 31)][ci = 8 j + 4 (lane >> 5) + e][tap]
+        for (int tap = 0; tap < FS_K; ++tap)
+            for (int j = 0; j < FS_H / 8; ++j)
+                for (int n = 0; n < 4; ++n)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = 32 * n + (lane & 31), ci = 8 * j + 4 * (lane >> 5) + e;
+                            wl[((((size_t)tap * (FS_H / 8) + j) * 4 + n) * 64 + lane) * 4 + e] = w.in[l][((size_t)co * FS_H + ci) * FS_K + tap];
+                        }
+        for (int c = 0; c < 2 * FS_H; ++c) wl[FS_IN_FRAGS + c] = w.bin[l][c];
+        float* wr = wl + FS_IN_FRAGS + 2 * FS_H;
+        const int n_out = last ? FS_H : 2 * FS_H;
+        for (int j = 0; j < FS_H / 8; ++j)
+            for (int n = 0; n < 4; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = 32 * n + (lane & 31), ci = 8 * j + 4 * (lane >> 5) + e;
+                        wr[(((size_t)j * 4 + n) * 64 + lane) * 4 + e] = co < n_out ? w.rs[l][(size_t)co * FS_H + ci] : 0.f;
+                    }
+        for (int c = 0; c < 2 * FS_H; ++c) wr[FS_RS_FRAGS + c] = c < n_out ? w.brs[l][c] : 0.f;
+    }
+    float* wq = o + FS_PRE + (size_t)layers * FS_LAYER;
+    for (int q = 0; q < FS_HALF; ++q)
+        for (int c = 0; c < FS_H; ++c) wq[q * FS_H + c] = w.post[(size_t)q * FS_H + c];
+    for (int q = 0; q < FS_HALF; ++q) wq[FS_HALF * FS_H + q] = w.bpost[q];
+}
+
+hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream) {
+    const int halo = p.n_flows * p.layers, RC = W - 2 * halo;
+    if (RC < 32 || p.Z != 2 * FS_HALF || p.z_in == p.z_out) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)flowstack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.T4 + RC - 1) / RC, p.B);
+    hipLaunchKernelGGL(flowstack_kernel, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace dtts
