@@ -12,7 +12,7 @@
 //   * contractions on v_mfma_f32_32x32x2_f32 (D[co][t]: A = weights, B = LDS rows); the K order is chosen so that a lane's four
 //     consecutive steps read four consecutive channels: one ds_read_b128 of the state and one 16 B weight fragment per co-tile
 //     feed 16 MFMAs.  Weights stream from L2 in fragment order (context.hip: flowstack_pack);
-//   * the conditioning (cond_layer(g) of all blocks: one [B*T4, 256] x [256, 2048] convolution, launched once before) enters as
+//   * the conditioning (cond_layer(g) of all blocks: one [B*T4, hidden] x [hidden, 2048] convolution, launched once before) enters as
 //     the accumulators' initial value together with the bias;
 //   * pre (8 -> 64) and post (64 -> 8) on the VALU; rows outside [0, T4) are forced to zero after every update = the
 //     convolutions' zero padding (the reference runs the flow with x_mask = 1 over the padded batch).
