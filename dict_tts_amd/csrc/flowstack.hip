@@ -309,6 +309,7 @@ void flowstack_pack(const FlowStackHostWeights& w, int layers, std::vector<float
 hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream) {
     const int halo = p.n_flows * p.layers, RC = W - 2 * halo;
     if (RC < 32 || p.Z != 2 * FS_HALF || p.z_in == p.z_out) return hipErrorInvalidValue;
+    if (p.T4 <= 0 || p.B <= 0) return hipSuccess;
     const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST) * sizeof(float);
     static bool configured = false;
     if (!configured) {
