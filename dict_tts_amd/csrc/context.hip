@@ -782,7 +782,7 @@ int run_encoder(dtts_ctx* h, const Encoder& E, float* x, float* hbuf, float* qkv
 // WN.forward with x_mask = 1 (modules/commons/wavenet.py:54-78): x is updated in place, `out` receives the skip sum
 // g == null: `cond` already holds the conditioning (the caller computed it)
 int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float* cond, float* acts, float* out, int B,
-           int T, hipStream_t s) {
+           int T, hipStream_t s, const int64_t* cond_m2w = nullptr, int cond_Tw = 0) {
     const int H = W.hidden;
     ConvParams p;
     if (g) {
@@ -799,6 +799,8 @@ int run_wn(dtts_ctx* h, const WNet& W, float* x, const float* g, int g_ld, float
                 v.cond = cond;
                 v.ld_cond = 2 * H * W.layers;
                 v.cond_coff = i * 2 * H;
+                v.cond_m2w = (const long long*)cond_m2w;   // word-level conditioning gathered in the epilogue (decoder)
+                v.cond_Tw = cond_Tw;
                 v.yf = acts;
                 v.ldyf = H;
                 LAUNCH(vconv_launch(v, s));
@@ -1733,11 +1735,10 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
     float* fh = A.alloc<float>(qrows * Hf);
     float* facts = A.alloc<float>(qrows * Hf);
     float* fout = A.alloc<float>(qrows * Hf);
-    float* dcond = A.alloc<float>(mrows * 2 * Hd * c.fvae_dec_n_layers);
     float* dx = A.alloc<float>(mrows * Hd);
     float* dacts = A.alloc<float>(mrows * Hd);
     float* dout = A.alloc<float>(mrows * Hd);
-    if (!g || !gs || !z || !fcond || !fh || !facts || !fout || !dcond || !dx || !dacts || !dout)
+    if (!g || !gs || !z || !fcond || !fh || !facts || !fout || !dx || !dacts || !dout)
         return fail(h, DTTS_E_NOMEM, "decoder workspace");
     // A7: gather-expand (x * tgt_nonpadding is implied: padded frames gather the zero row)
     LAUNCH(expand_launch(h->weo, h->m2w, g, h->x_mask, B, h->T_w, T, C, s));
@@ -1796,15 +1797,24 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
     // output (or the zero row): the convolution is applied to the B*T_w word rows (33x fewer than the B*T frames) and its
     // output gathered by mel2word; frames with mel2word == 0 get conv(0) = bias.  Bit-identical: every output row of this
     // kernel depends only on its own input row, summed in the same order whatever the tile shape.
-    {
-        const int CW = 2 * Hd * c.fvae_dec_n_layers;
-        float* cond_w = A.alloc<float>((size_t)B * h->T_w * CW);
-        if (!cond_w) return fail(h, DTTS_E_NOMEM, "decoder workspace");
-        p = base_params(h->weo, C, B, h->T_w, h->T_w, cond_w, CW);
-        LAUNCH(conv1d_launch(h->dec_wn.cond, p, s));
-        LAUNCH(expand_launch(cond_w, h->m2w, dcond, nullptr, B, h->T_w, T, CW, s, h->dec_wn.cond.bias));
+    const int CW = 2 * Hd * c.fvae_dec_n_layers;
+    float* cond_w = A.alloc<float>(((size_t)B * h->T_w + 1) * CW);   // row 0: conv(0) = the bias, rows 1..: the B*T_w word rows
+    if (!cond_w) return fail(h, DTTS_E_NOMEM, "decoder workspace");
+    if (hipMemcpyAsync(cond_w, h->dec_wn.cond.bias, (size_t)CW * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail(h, DTTS_E_HIP, "decoder conditioning bias row");
+    p = base_params(h->weo, C, B, h->T_w, h->T_w, cond_w + CW, CW);
+    LAUNCH(conv1d_launch(h->dec_wn.cond, p, s));
+    int rc;
+    if (!h->dec_wn.in.empty() && h->dec_wn.in[0].engine == ENG_BF16X3) {
+        // split-operand layers: every layer's epilogue gathers its conditioning row by mel2word from the word-level tensor (L2-resident,
+        // B*T_w rows) — the [B*T, 2*Hd*layers] expansion (221 MB written and read back at B=60) never exists
+        rc = run_wn(h, h->dec_wn, dx, nullptr, C, cond_w, dacts, dout, B, T, s, h->m2w, h->T_w);
+    } else {
+        float* dcond = A.alloc<float>(mrows * CW);
+        if (!dcond) return fail(h, DTTS_E_NOMEM, "decoder workspace");
+        LAUNCH(expand_launch(cond_w + CW, h->m2w, dcond, nullptr, B, h->T_w, T, CW, s, h->dec_wn.cond.bias));
+        rc = run_wn(h, h->dec_wn, dx, nullptr, C, dcond, dacts, dout, B, T, s);
     }
-    int rc = run_wn(h, h->dec_wn, dx, nullptr, C, dcond, dacts, dout, B, T, s);
     if (rc) return rc;
     p = base_params(dout, Hd, B, T, T, mel_out, c.audio_num_mel_bins);
     if (mel_cap) {

@@ -31,6 +31,9 @@ struct VConvParams {
     const float* gbias;
     const float* cond;        // gated: conditioning [B][T][ld_cond], channels cond_coff + (c | gate_H + c)
     int ld_cond, cond_coff;
+    const long long* cond_m2w; // optional [B][T]: the conditioning row of frame (b, t) is cond row b * cond_Tw + m2w (1-based word index), or row 0
+    int cond_Tw;              //           for m2w outside 1..cond_Tw (padding frames: row 0 holds conv(0) = the bias) — the gather-expand of the
+                              //           word-level conditioning folded into the epilogue instead of a [B*T, ld_cond] tensor in HBM
     int split;                // > 0: output channels >= split go to the second segment (column - split): WaveNet res / skip
     float* yf2;
     int ldyf2;

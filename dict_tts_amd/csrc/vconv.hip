@@ -243,7 +243,12 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
                         o += *(const f32x4*)(p.gbias + co);
                         g += *(const f32x4*)(p.gbias + p.gate_H + co);
                         if (p.cond) {
-                            const float* c = p.cond + row * p.ld_cond + p.cond_coff;
+                            long long crow = row;
+                            if (p.cond_m2w) {
+                                const long long w = p.cond_m2w[row];
+                                crow = (w > 0 && w <= p.cond_Tw) ? (long long)b * p.cond_Tw + w : 0;
+                            }
+                            const float* c = p.cond + crow * p.ld_cond + p.cond_coff;
                             o += *(const f32x4*)(c + co);
                             g += *(const f32x4*)(c + p.gate_H + co);
                         }
