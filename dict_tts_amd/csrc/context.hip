@@ -530,7 +530,7 @@ int build_acoustic(dtts_ctx* h) {
             const size_t n_c = (size_t)2 * Hf * c.prior_glow_n_layers;
             if (fuse_flows && (!wc || wc->f.size() != n_c * c.hidden_size || bc.size() != n_c)) fuse_flows = false;
             if (fuse_flows) {
-                flowstack_pack(fw, c.prior_glow_n_layers, fs_host);
+                flowstack_pack(fw, c.prior_glow_n_layers, !c.decoder_fp32, fs_host);
                 fs_cond_w.insert(fs_cond_w.end(), wc->f.begin(), wc->f.end());
                 fs_cond_b.insert(fs_cond_b.end(), bc.begin(), bc.end());
             }
@@ -1771,6 +1771,7 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
         fp.Z = Z;
         fp.n_flows = (int)h->flows.size();
         fp.layers = c.prior_glow_n_layers;
+        fp.x3 = c.decoder_fp32 ? 0 : 1;   // split-bf16 like the decoder WaveNet unless the exact-fp32 decoder was asked for
         for (size_t i = 0; i < h->flows.size(); ++i) {
             fp.in_coff[i] = h->flows[i].in_coff;
             fp.out_coff[i] = h->flows[i].out_coff;

@@ -30,6 +30,7 @@ struct FlowStackParams {
     const float* w;       // n_flows * fs_flow_floats(layers) floats
     int B, T4, Z;
     int n_flows, layers;
+    int x3;               // 1: weights packed as bf16 hi / lo fragments, contractions on three bf16 MFMAs per product; 0: exact fp32 MFMA
     int in_coff[FS_MAX_FLOWS], out_coff[FS_MAX_FLOWS];   // physical channel offsets of the logical x0 / x1 halves (flip parity)
 };
 
@@ -39,7 +40,7 @@ struct FlowStackHostWeights {
     std::vector<float> pre, bpre, post, bpost;
     std::vector<std::vector<float>> in, bin, rs, brs;
 };
-void flowstack_pack(const FlowStackHostWeights& w, int layers, std::vector<float>& out);   // appends fs_flow_floats(layers) floats
+void flowstack_pack(const FlowStackHostWeights& w, int layers, bool x3, std::vector<float>& out);   // appends fs_flow_floats(layers) floats
 
 bool flowstack_supported(int hidden, int kernel, int layers, int blocks, int latent);
 hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream);

@@ -17,8 +17,10 @@
 //   * pre (8 -> 64) and post (64 -> 8) on the VALU; rows outside [0, T4) are forced to zero after every update = the
 //     convolutions' zero padding (the reference runs the flow with x_mask = 1 over the padded batch).
 #include "flowstack.h"
+#include "rb_common.h"
 
 #include <algorithm>
+#include <cstring>
 
 namespace dtts {
 
@@ -31,6 +33,10 @@ constexpr int HP = FS_H + 4;           // LDS row pitch of h / acts (floats): 27
 constexpr int ZP = 16;                 // z row (floats)
 }
 
+// X3: the two convolutions of every layer on v_mfma_f32_32x32x16_bf16 with bf16 hi / lo split operands (Wlo*Xhi + Whi*Xlo + Whi*Xhi: 16-bit
+// significand products, fp32 accumulation — the decoder WaveNet's arithmetic, 5.3x the fp32-MFMA rate); the fp32 rows in LDS are split
+// on the fly (8 values per lane and fragment).  X3 = false: exact fp32 MFMA (dtts_config.decoder_fp32).
+template <bool X3>
 __global__ __launch_bounds__(256, 1) void flowstack_kernel(const FlowStackParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* zt = (float*)smem_raw;                       // [W][ZP]
@@ -59,6 +65,20 @@ __global__ __launch_bounds__(256, 1) void flowstack_kernel(const FlowStackParams
     for (int i = tid; i < 2 * HP; i += 256) hb[(i < HP ? 0 : (W + 1) * HP - HP) + i] = 0.f;
     float* hrow = hb + (1 + row_l) * HP;               // this lane's row of the state
     float* arow = ab + row_l * HP;
+    // 8 consecutive fp32 values of an LDS row -> bf16 hi / lo fragments (round-to-nearest-even both)
+    auto split8 = [&](const float* src, uint4& hi, uint4& lo) {
+        const fs4 v0 = *(const fs4*)src, v1 = *(const fs4*)(src + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        unsigned hb[8];
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            hb[i] = rf2bf(v[i]);
+            r[i] = v[i] - __builtin_bit_cast(float, hb[i] << 16);
+        }
+        hi = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+        lo = make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
+    };
 
     // this lane's conditioning of layer g = block * layers + layer (its row, its 64 of the 128 gate channels), fetched one layer ahead
     fs4 cnd[4][4];
@@ -127,6 +147,44 @@ __global__ __launch_bounds__(256, 1) void flowstack_kernel(const FlowStackParams
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
                 }
+            if constexpr (X3) {
+                // fragment f = (tap * 4 + kb) * 4 + n: hi at uint4 index (2f) * 64 + lane, lo at (2f + 1) * 64 + lane; PFD steps ahead
+                constexpr int NIT = FS_K * (FS_H / 16), PFD = 2;
+                const uint4* wq = (const uint4*)wl + lane;
+                uint4 ah[PFD + 1][4], al[PFD + 1][4];
+#pragma unroll
+                for (int s0 = 0; s0 < PFD; ++s0)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        ah[s0][n] = wq[(2 * (s0 * 4 + n)) * 64];
+                        al[s0][n] = wq[(2 * (s0 * 4 + n) + 1) * 64];
+                    }
+                uint4 xh, xl;
+                split8(hrow - HP + 8 * half, xh, xl);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (it + PFD < NIT) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            ah[(it + PFD) % (PFD + 1)][n] = wq[(2 * ((it + PFD) * 4 + n)) * 64];
+                            al[(it + PFD) % (PFD + 1)][n] = wq[(2 * ((it + PFD) * 4 + n) + 1) * 64];
+                        }
+                    }
+                    uint4 nh = xh, nl = xl;
+                    if (it + 1 < NIT) {
+                        const int tap = (it + 1) / (FS_H / 16), kb = (it + 1) % (FS_H / 16);
+                        split8(hrow + (tap - 1) * HP + 16 * kb + 8 * half, nh, nl);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[n] = mfma16<EL_BF16>(al[it % (PFD + 1)][n], xh, acc[n]);
+                        acc[n] = mfma16<EL_BF16>(ah[it % (PFD + 1)][n], xl, acc[n]);
+                        acc[n] = mfma16<EL_BF16>(ah[it % (PFD + 1)][n], xh, acc[n]);
+                    }
+                    xh = nh;
+                    xl = nl;
+                }
+            } else
             {
                 // weight fragments run PFD steps ahead through a register ring (L2 latency under the MFMAs); the state row one step ahead
                 constexpr int NIT = FS_K * (FS_H / 8), PFD = 3;
@@ -181,6 +239,27 @@ __global__ __launch_bounds__(256, 1) void flowstack_kernel(const FlowStackParams
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
                 }
+            if constexpr (X3) {
+                constexpr int NIT = FS_H / 16;
+                const uint4* wq = (const uint4*)(wl + FS_IN_FRAGS + 2 * FS_H) + lane;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    uint4 ah[4], al[4], xh, xl;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        ah[n] = (n < nrs) ? wq[(2 * (it * 4 + n)) * 64] : make_uint4(0, 0, 0, 0);
+                        al[n] = (n < nrs) ? wq[(2 * (it * 4 + n) + 1) * 64] : make_uint4(0, 0, 0, 0);
+                    }
+                    split8(arow + 16 * it + 8 * half, xh, xl);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (n >= 2 && last) continue;
+                        acc[n] = mfma16<EL_BF16>(al[n], xh, acc[n]);
+                        acc[n] = mfma16<EL_BF16>(ah[n], xl, acc[n]);
+                        acc[n] = mfma16<EL_BF16>(ah[n], xh, acc[n]);
+                    }
+                }
+            } else
             {
                 constexpr int NIT = FS_H / 8, PFD = 3;
                 fs4 a[PFD + 1][4];
@@ -269,7 +348,20 @@ bool flowstack_supported(int hidden, int kernel, int layers, int blocks, int lat
            blocks <= FS_MAX_FLOWS && 2 * blocks * layers <= W - 32;
 }
 
-void flowstack_pack(const FlowStackHostWeights& w, int layers, std::vector<float>& out) {
+static unsigned short fs_bf16(float f) {   // round-to-nearest-even
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float fs_bf16_f(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void flowstack_pack(const FlowStackHostWeights& w, int layers, bool x3, std::vector<float>& out) {
     const size_t base = out.size();
     out.resize(base + fs_flow_floats(layers), 0.f);
     float* o = out.data() + base;
@@ -279,6 +371,36 @@ void flowstack_pack(const FlowStackHostWeights& w, int layers, std::vector<float
     for (int l = 0; l < layers; ++l) {
         float* wl = o + FS_PRE + (size_t)l * FS_LAYER;
         const bool last = l == layers - 1;
+        if (x3) {
+            // split-operand form: fragment f = (tap * 4 + kb) * 4 + n (in_layer) / kb * 4 + n (res_skip): 8 bf16 hi at uint4 (2f) * 64 + lane,
+            // 8 bf16 lo at (2f + 1) * 64 + lane; element i = W[co = 32 n + (lane & 31)][ci = 16 kb + 8 (lane >> 5) + i][tap]
+            auto put = [&](float* dst, size_t f, int lane, int i, float v) {
+                unsigned short* hi = (unsigned short*)(dst + ((2 * f) * 64 + lane) * 4);
+                unsigned short* lo = (unsigned short*)(dst + ((2 * f + 1) * 64 + lane) * 4);
+                hi[i] = fs_bf16(v);
+                lo[i] = fs_bf16(v - fs_bf16_f(hi[i]));
+            };
+            const int n_out = last ? FS_H : 2 * FS_H;
+            for (int tap = 0; tap < FS_K; ++tap)
+                for (int kb = 0; kb < FS_H / 16; ++kb)
+                    for (int n = 0; n < 4; ++n)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const int co = 32 * n + (lane & 31), ci = 16 * kb + 8 * (lane >> 5) + i;
+                                put(wl, ((size_t)tap * (FS_H / 16) + kb) * 4 + n, lane, i, w.in[l][((size_t)co * FS_H + ci) * FS_K + tap]);
+                            }
+            for (int c = 0; c < 2 * FS_H; ++c) wl[FS_IN_FRAGS + c] = w.bin[l][c];
+            float* wr = wl + FS_IN_FRAGS + 2 * FS_H;
+            for (int kb = 0; kb < FS_H / 16; ++kb)
+                for (int n = 0; n < 4; ++n)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int co = 32 * n + (lane & 31), ci = 16 * kb + 8 * (lane >> 5) + i;
+                            put(wr, (size_t)kb * 4 + n, lane, i, co < n_out ? w.rs[l][(size_t)co * FS_H + ci] : 0.f);
+                        }
+            for (int c = 0; c < 2 * FS_H; ++c) wr[FS_RS_FRAGS + c] = c < n_out ? w.brs[l][c] : 0.f;
+            continue;
+        }
         // fragment(tap, j, n, lane)[e] = W[co = 32 n + (lane & 31)][ci = 8 j + 4 (lane >> 5) + e][tap]
         for (int tap = 0; tap < FS_K; ++tap)
             for (int j = 0; j < FS_H / 8; ++j)
@@ -313,12 +435,14 @@ hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream) {
     const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)flowstack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)flowstack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flowstack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured = true;
     }
     dim3 grid((p.T4 + RC - 1) / RC, p.B);
-    hipLaunchKernelGGL(flowstack_kernel, grid, dim3(256), lds, stream, p);
+    if (p.x3) hipLaunchKernelGGL(flowstack_kernel<true>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(flowstack_kernel<false>, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
