@@ -143,6 +143,27 @@ def test_teacher_forced_mel2word_and_batch_padding_semantics(acoustic, oracle_sd
     assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3   # ALL frames, padded ones included
 
 
+def test_fused_prior_flow_equals_launch_by_launch(acoustic, monkeypatch):
+    """the prior flow as one kernel (flowstack.hip: split-bf16 contractions, hardware exp2 / rcp in the gate) against the same flow launch by
+    launch on the generic exact-fp32 kernels (DTTS_TUNE bit 8, read when a context is created): same noise, same durations, mel within a
+    tenth of the reference tolerance on every frame incl. the padded ones and the chunk seams (T_mel/4 > 96 rows: two chunks per utterance)"""
+    from dict_tts_amd import model
+    monkeypatch.setenv("DTTS_TUNE", "256")
+    plain = model.PortaSpeech_dict(hparams={})
+    plain.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()}, strict=True)
+    monkeypatch.delenv("DTTS_TUNE")
+    batch = synth.biaobei_batch(4, 6, gc.SEED)
+    m2w = synth.teacher_mel2word(batch["word_tokens"], 45, 9)     # long utterances: 45 frames per word
+    T_mel = m2w.shape[1] + (-m2w.shape[1]) % 4
+    z = T(synth.noise(13, 6, T_mel // 4))
+    a = _run(acoustic, batch, z=z, mel2word=T(m2w))
+    b = _run(plain, batch, z=z, mel2word=T(m2w))
+    assert a["mel_out"].shape == b["mel_out"].shape and a["mel_out"].shape[1] // 4 > 96
+    assert torch.equal(a["mel2word"].cpu(), b["mel2word"].cpu())
+    d = float((a["mel_out"] - b["mel_out"]).abs().max())
+    assert 0.0 < d <= 1e-4, d       # different arithmetic (so not identical), far inside the 1e-3 gate
+
+
 def test_length_regulator_device_vs_reference_golden(golden_dir):
     """G3 integer semantics on the device kernels through dtts_length_regulate: the reference's mel2word for crafted
     integer durations (zeros in the middle, an all-zero utterance -> ones, ilens shorter than T_w), and torch.round's
