@@ -23,7 +23,10 @@ __device__ __forceinline__ unsigned f2bf(float f) {  // round-to-nearest-even fp
 }
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 
-template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
+// FULL: the whole input width C_in_pad is staged ONCE (LDS rows of C_in_pad elements) and the CK-chunks are contracted from it back to
+// back in the same order — bit-identical to the chunk-by-chunk form, without its per-chunk staging round trip and two barriers.  For the
+// short-sequence configurations (one workgroup per CU, one wave per SIMD: nothing else hides those latencies).
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK, bool FULL = false>
 __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
     const int in0 = t0 * p.stride - p.pad;
     const int NG = p.C_in_pad / KG;
-    char* lds_lo = smem + (size_t)rows * PITCH;
+    const int pitch = FULL ? p.C_in_pad * ES + 16 : PITCH;   // (C_in_pad * ES + 16) mod 256 == 16 as well for the widths in use: same bank spread
+    char* lds_lo = smem + (size_t)rows * pitch;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -58,47 +62,56 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     const float* xb = p.x + (long long)b * p.x_bstride + p.x_coff;
     const bool live = t0 < out_len;
 
-    if (live)
-        for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
-            // ---- stage X[in0 .. in0+rows) x [ci0, ci0+CK) into LDS (pre-activation, zero padding, conversion)
-            {   // batches of U independent 16 B loads in flight per thread, then conversion + LDS writes
-                constexpr int U = 4, PIECES = CK / 4;
-                const int total = rows * PIECES;
-                for (int base = tid; base < total; base += 256 * U) {
-                    f32x4 vv[U];
+    // ---- stage X[in0 .. in0+rows) x [ci0, ci0 + width) into LDS columns [col0, col0 + width) (pre-activation, zero padding, conversion):
+    // batches of U independent 16 B loads in flight per thread, then conversion + LDS writes
+    auto stage = [&](int ci0, int width, int col0) {
+        constexpr int U = 4;
+        const int PIECES = FULL ? width / 4 : CK / 4;
+        const int total = rows * PIECES;
+        for (int base = tid; base < total; base += 256 * U) {
+            f32x4 vv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int idx = base + u * 256;
-                        const int r = idx / PIECES, c4 = idx % PIECES;
-                        const int t = in0 + r, ci = ci0 + c4 * 4;
-                        vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (idx < total && t >= 0 && t < in_len && ci < p.C_in) vv[u] = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
-                    }
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const int r = idx / PIECES, c4 = idx % PIECES;
+                const int t = in0 + r, ci = ci0 + c4 * 4;
+                vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < total && t >= 0 && t < in_len && ci < p.C_in) vv[u] = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
+            }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int idx = base + u * 256;
-                        if (idx >= total) continue;
-                        const int r = idx / PIECES, c4 = idx % PIECES;
-                        f32x4 v = vv[u];
-                        if (p.pre_act) {
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                if (idx >= total) continue;
+                const int r = idx / PIECES, c4 = idx % PIECES + col0 / 4;
+                f32x4 v = vv[u];
+                if (p.pre_act) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
-                        }
-                        if constexpr (ENGINE == ENG_F32) {
-                            *(f32x4*)(smem + r * PITCH + c4 * 16) = v;
-                        } else {
-                            unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
-                            *(uint2*)(smem + r * PITCH + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                            if constexpr (ENGINE == ENG_BF16X3) {
-                                unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
-                                unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
-                                *(uint2*)(lds_lo + r * PITCH + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
-                            }
-                        }
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+                }
+                if constexpr (ENGINE == ENG_F32) {
+                    *(f32x4*)(smem + r * pitch + c4 * 16) = v;
+                } else {
+                    unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+                    *(uint2*)(smem + r * pitch + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    if constexpr (ENGINE == ENG_BF16X3) {
+                        unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
+                        unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
+                        *(uint2*)(lds_lo + r * pitch + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
                     }
                 }
             }
+        }
+    };
+    if (live) {
+        if constexpr (FULL) {
+            stage(0, p.C_in_pad, 0);
             __syncthreads();
+        }
+        for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
+            if constexpr (!FULL) {
+                stage(ci0, CK, 0);
+                __syncthreads();
+            }
             // ---- contraction over taps and k-groups of this chunk.  Steps s = tap * NKG + kg; weight fragments
             // run PF steps ahead in a register ring, activation fragments one step ahead (double buffer); the
             // sched_barriers keep those prefetches above the MFMAs of the current step.
@@ -123,14 +136,14 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                         if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[off + ctc[n] * 64];
                     }
                 };
-                const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * PITCH + (lane >> 5) * (KG / 2) * ES;
+                const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + (FULL ? ci0 * ES : 0);
                 auto load_x = [&](uint4 (&dh)[MT], uint4 (&dl)[MT], int s) {
                     const int sc = s < S ? s : S - 1;
-                    const int off = abase + (sc / NKG) * p.dil * PITCH + (sc % NKG) * KG * ES;
+                    const int off = abase + (sc / NKG) * p.dil * pitch + (sc % NKG) * KG * ES;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        dh[m] = *(const uint4*)(smem + off + m * 32 * p.stride * PITCH);
-                        if constexpr (ENGINE == ENG_BF16X3) dl[m] = *(const uint4*)(lds_lo + off + m * 32 * p.stride * PITCH);
+                        dh[m] = *(const uint4*)(smem + off + m * 32 * p.stride * pitch);
+                        if constexpr (ENGINE == ENG_BF16X3) dl[m] = *(const uint4*)(lds_lo + off + m * 32 * p.stride * pitch);
                     }
                 };
                 uint4 rh[R][NT], rl[R][NT], xh[2][MT], xl[2][MT];
@@ -172,8 +185,9 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (!FULL) __syncthreads();
         }
+    }
 
     // ---- epilogue
     const int col = lane & 31;
@@ -231,14 +245,14 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     }
 }
 
-template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK, bool FULL = false>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
     constexpr int PITCH = CK * ES + 16;
     constexpr int TT = 32 * MT * WT, CO_T = 32 * NT * WC;
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
-    size_t lds = (size_t)rows * PITCH * (ENGINE == ENG_BF16X3 ? 2 : 1);
-    auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK>;
+    size_t lds = (size_t)rows * (FULL ? p.C_in_pad * ES + 16 : PITCH) * (ENGINE == ENG_BF16X3 ? 2 : 1);
+    auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK, FULL>;
     static size_t configured = 0;
     if (lds > 65536 && lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -256,8 +270,10 @@ static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStr
         // short sequences (the T_w ~ 27 encoder, B = 1): latency-bound by the serial fp32 MFMA chain of one wave (64 cycles per
         // 32x32x2 MFMA); one co-tile per wave halves that chain at twice the workgroups (bit-identical: the order over K is unchanged)
         // (gated layers keep two co-tiles per wave: the tanh tile and its sigmoid partner meet in the epilogue)
-        if (p.T_out <= 64 && !p.gate_H) return launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);  // 32 t x 128 co
-        if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);                 // 32 t x 256 co
+        // (FULL: the input tile is staged once for all its CK-chunks, while the rows fit the LDS)
+        const bool full = p.C_in_pad > CK && ((size_t)(31 * p.stride + (p.K - 1) * p.dil + 1) * (p.C_in_pad * 4 + 16) <= 150 * 1024);
+        if (p.T_out <= 64 && !p.gate_H) return full ? launch_cfg<ENGINE, 1, 1, 1, 4, CK, true>(p, stream) : launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);  // 32 t x 128 co
+        if (p.T_out <= 64) return full ? launch_cfg<ENGINE, 1, 2, 1, 4, CK, true>(p, stream) : launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);   // 32 t x 256 co
         return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                      // 128 t x 64 co
     } else {
         if (L.C_out_pad <= 32) return launch_cfg<ENGINE, 2, 1, 4, 1, CK>(p, stream);   // 256 t x 32 co
