@@ -24,7 +24,7 @@ template <int C, int TT, int EL>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = TT == 192 ? 3 : 4, NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
+    constexpr int MT = (TT == 192 || TT == 96) ? 3 : 4, NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
@@ -301,9 +301,18 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifndef VP_TT96
+#define VP_TT96 1
+#endif
 template <int EL>
 static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t stream) {
-    if (C == 256) return vpair_launch_tt<256, 128, EL>(p, stream);
+    if (C == 256) {
+        // 128-row tiles, or 96-row ones where only those leave room for TWO workgroups per CU (one workgroup = one wave per SIMD exposes
+        // every latency of the memory phases: k = 7 with dilation 5, k = 11 with dilation 3)
+        auto lds_of = [&](int tt) { return ((size_t)tt + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 4)) * (256 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int); };
+        if (2 * lds_of(128) > 160 * 1024 && 2 * lds_of(96) <= 160 * 1024 && VP_TT96) return vpair_launch_tt<256, 96, EL>(p, stream);
+        return vpair_launch_tt<256, 128, EL>(p, stream);
+    }
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
     const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
