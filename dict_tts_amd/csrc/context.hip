@@ -1379,7 +1379,11 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     const dtts_config& c = h->cfg;
     const int nup = c.n_upsamples, nk = c.n_resblock_kernels;
     Timed t_voc(h, DTTS_TIMER_STAGE_HIFIGAN, s);   // 'hifigan' (vocoders/hifigan.py:59): the generator forward
-    if (c.vocoder_precision != DTTS_VOC_BF16X3) return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
+    if (c.vocoder_precision != DTTS_VOC_BF16X3) {
+        // the fused kernels' persistent workgroups keep a per-utterance tile table (12 B per utterance) in LDS beside their tiles
+        if (B > DTTS_MAX_VOCODER_BATCH) return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: B = %d exceeds %d utterances per call", B, DTTS_MAX_VOCODER_BATCH);
+        return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
+    }
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
     {

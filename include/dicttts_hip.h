@@ -217,8 +217,9 @@ int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ile
  * Vocoder — replaces HifiGanGenerator.forward as used by HifiGAN.spec2wav (vocoders/hifigan.py:54-62), for a
  * batch: mel [B,T,80] f32 (the layout of ret['mel_out'] and of spec2wav's argument), lens [B] i32 valid
  * frames per utterance (NULL = T for all).  wav [B, T*hop] f32; utterance b is exactly what the reference
- * produces for mel[b,:lens[b]] alone, samples past lens[b]*hop are zero.
+ * produces for mel[b,:lens[b]] alone, samples past lens[b]*hop are zero.  B <= DTTS_MAX_VOCODER_BATCH per call in the fused modes.
  */
+#define DTTS_MAX_VOCODER_BATCH 2048
 int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* lens_dev, int B, int T, float* wav_dev,
                          dtts_stream stream);
 int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */

@@ -738,6 +738,10 @@ def test_abi_misuse_fails_loudly(voc_sd):
         m.ctx.text2mel_encode_ids(buf.data_ptr(), buf.data_ptr(), None, None, 1, 2, 8, 4, s)
     with pytest.raises(abi.DttsError, match="vocoder weights not finalized"):   # acoustic-only handle has no vocoder
         m.ctx.hifigan_forward(buf.data_ptr(), None, 1, 4, buf.data_ptr(), s)
+    from dict_tts_amd import vocoder
+    v = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config())
+    with pytest.raises(abi.DttsError, match="utterances per call"):             # the fused kernels' tile table is sized per utterance
+        v.ctx.hifigan_forward(buf.data_ptr(), None, 4096, 4, buf.data_ptr(), s)
     with pytest.raises(abi.DttsError, match="FFT block weights not finalized"):
         m.ctx.fft_blocks_forward(buf.data_ptr(), None, None, 0, 1, 4, buf.data_ptr(), s)
     with pytest.raises(NotImplementedError):
