@@ -23,7 +23,7 @@ EXPORTS = ["dtts_default_config", "dtts_config_sizeof", "dtts_create", "dtts_des
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
            "dtts_load_weights", "dtts_text2mel_plan", "dtts_text2mel_forward", "dtts_text2mel_forward_ids",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
-           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset"]
+           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset", "dtts_set_noise_seed", "dtts_vocoder_range_guard", "dtts_vocoder_clamped"]
 
 
 class DttsConfig(C.Structure):
@@ -37,7 +37,8 @@ class DttsConfig(C.Structure):
         ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("n_resblock_kernels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
         ("vocoder_precision", C.c_int32), ("fft_layers", C.c_int32), ("fft_kernel_size", C.c_int32),
-        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32), ("decoder_fp32", C.c_int32)]
+        ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32), ("decoder_fp32", C.c_int32),
+        ("vocoder_range_guard", C.c_int32)]
 
 
 class DttsError(RuntimeError):
@@ -84,6 +85,9 @@ def load_library(path=None):
     lib.dtts_timer_enable.argtypes = [vp, i32]
     lib.dtts_timer_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dtts_timer_reset.argtypes = [vp]
+    lib.dtts_set_noise_seed.argtypes = [vp, C.c_uint64]
+    lib.dtts_vocoder_range_guard.argtypes = [vp, i32]
+    lib.dtts_vocoder_clamped.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
     _lib = lib
     return lib
 
@@ -213,3 +217,16 @@ class Context:
 
     def timer_reset(self):
         self._chk(self.lib.dtts_timer_reset(self.h), "dtts_timer_reset")
+
+    def set_noise_seed(self, seed):
+        """seed of the device-side prior sample (z_p == NULL); contexts otherwise start from a time / pid / device dependent seed"""
+        self._chk(self.lib.dtts_set_noise_seed(self.h, int(seed) & (2 ** 64 - 1)), "dtts_set_noise_seed")
+
+    def vocoder_range_guard(self, enable):
+        self._chk(self.lib.dtts_vocoder_range_guard(self.h, int(bool(enable))), "dtts_vocoder_range_guard")
+
+    def vocoder_clamped(self, stream, reset=True):
+        """activations the fp16 ResBlock operands could not represent since the last reset (synchronises the stream)"""
+        n = C.c_int64(0)
+        self._chk(self.lib.dtts_vocoder_clamped(self.h, C.byref(n), int(bool(reset)), stream), "dtts_vocoder_clamped")
+        return n.value

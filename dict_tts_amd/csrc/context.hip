@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <ctime>
 #include <functional>
+#include <unistd.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -116,7 +118,7 @@ struct dtts_ctx {
     // ---- acoustic model
     float *word_emb = nullptr, *pinyin_emb = nullptr;
     Encoder sem, lin;
-    PackedConv s2_q, s2_kT, s2_v, s2_o;
+    PackedConv s2_q, s2_kT, s2_k, s2_v, s2_o;   // s2_kT: k_transform applied transposed to the query (tensor API); s2_k: to the table rows at upload
     std::vector<PackedConv> dur_conv;
     std::vector<float*> dur_g, dur_b;
     float *dur_w = nullptr, *dur_bias = nullptr;
@@ -136,7 +138,10 @@ struct dtts_ctx {
     // ---- workspaces and per-call state
     Arena a_enc, a_dec, a_voc;
     unsigned* amax_bits = nullptr;  // dtts_wav_to_int16 scratch
-    unsigned long long noise_counter = 0x5EEDull;   // device prior samples (z_p == NULL): one stream per call
+    unsigned long long noise_counter = 0x5EEDull;   // device prior samples (z_p == NULL): one stream per call, offset by noise_seed
+    unsigned long long noise_seed = 0;              // per context (dtts_create: time, pid, device, instance; dtts_set_noise_seed overrides)
+    unsigned long long* ovf_dev = nullptr;          // fp16 range guard counter (DTTS_VOC_F16), device
+    bool guard_on = false;
     int amax_cap = 0;
     int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
     bool encoded = false;
@@ -148,6 +153,7 @@ struct dtts_ctx {
     int t_entries = 0;
     int *t_off = nullptr, *t_poff = nullptr, *t_pmmax = nullptr;
     float *t_keys = nullptr, *t_values = nullptr, *t_key_map = nullptr;
+    bool t_projected = false;   // t_keys / t_values hold K = key Wk^T and V = value Wv^T (hidden_size wide) instead of the raw gloss rows
     int64_t *t_pinyin = nullptr, *t_pinyin_map = nullptr;
 };
 
@@ -449,6 +455,7 @@ int build_acoustic(dtts_ctx* h) {
         const float *pq = wq->f.data(), *pk = wk->f.data(), *pv = wv->f.data(), *po = wo->f.data();
         ok = ok && pack_conv(h, h->s2_q, ENG_F32, H, H, 1, [=](int co, int ci, int) { return pq[(size_t)co * H + ci]; }, {}, 1, 1, 0);
         ok = ok && pack_conv(h, h->s2_kT, ENG_F32, D, H, 1, [=](int co, int ci, int) { return pk[(size_t)ci * D + co]; }, {}, 1, 1, 0);
+        ok = ok && pack_conv(h, h->s2_k, ENG_F32, H, D, 1, [=](int co, int ci, int) { return pk[(size_t)co * D + ci]; }, {}, 1, 1, 0);
         ok = ok && pack_conv(h, h->s2_v, ENG_F32, H, D, 1, [=](int co, int ci, int) { return pv[(size_t)co * D + ci]; }, {}, 1, 1, 0);
         ok = ok && pack_conv(h, h->s2_o, ENG_F32, H, H, 1, [=](int co, int ci, int) { return po[(size_t)co * H + ci]; }, {}, 1, 1, 0);
     } else
@@ -565,6 +572,14 @@ int build_vocoder(dtts_ctx* h) {
     // DTTS_VOC_F16 (default): the six serial convolutions on bf16 hi/lo split operands, the ResBlocks on fp16 operands
     if (c.vocoder_precision != DTTS_VOC_BF16 && c.vocoder_precision != DTTS_VOC_BF16X3 && c.vocoder_precision != DTTS_VOC_F16)
         return fail(h, DTTS_E_INVAL, "vocoder_precision %d is not one of DTTS_VOC_BF16 / _BF16X3 / _F16", c.vocoder_precision);
+    // the split-operand staging of conv_pre reads the caller's mel rows with 16-byte loads (vconv.hip): the row width must keep them aligned
+    if (c.vocoder_precision == DTTS_VOC_F16 && c.audio_num_mel_bins % 4)
+        return fail(h, DTTS_E_INVAL, "DTTS_VOC_F16 needs audio_num_mel_bins %% 4 == 0 (got %d); use DTTS_VOC_BF16X3", c.audio_num_mel_bins);
+    if (!h->ovf_dev) {
+        if (hipMalloc((void**)&h->ovf_dev, sizeof(unsigned long long)) != hipSuccess || hipMemset(h->ovf_dev, 0, sizeof(unsigned long long)) != hipSuccess)
+            return fail(h, DTTS_E_NOMEM, "range-guard counter");
+        h->allocs.push_back(h->ovf_dev);
+    }
     const int eng = c.vocoder_precision == DTTS_VOC_BF16 ? ENG_BF16 : ENG_BF16X3;                                   // serial convolutions
     const int eng_rb = c.vocoder_precision == DTTS_VOC_F16 ? ENG_F16 : eng;                                         // ResBlock convolutions
     const std::string v = "vocoder.";
@@ -888,7 +903,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         for (int i = 0; i < nup; ++i) {
             rows *= c.upsample_rates[i];
             ch /= 2;
-            max_elems = std::max<size_t>(max_elems, (size_t)B * rows * ch);
+            max_elems = std::max<size_t>(max_elems, (size_t)B * ((rows + 31) & ~(size_t)31) * ch);   // (blocked tensors pad to 32 rows per utterance)
         }
     }
     const int melC = h->conv_pre.C_in_pad;
@@ -995,6 +1010,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     post_done = true;
                 }
                 rp.el = el;
+                rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
                 Timed tm(h, TV, s);
@@ -1020,6 +1036,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     vp.div = (float)nk;
                     vp.slope = last_stage ? 0.01f : 0.1f;
                     vp.el = el;
+                    vp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
                     vp.dbg = g_ablate >> 8;
 #ifdef DTTS_ABLATE
                     if (getenv("DTTS_VP_STATS")) {   // per-phase cycles of wave 0 (staging, c1, rewrite, c2, epilogue incl. store acks), printed per launch
@@ -1029,6 +1046,10 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                         vp.stats = dstats;
                     }
 #endif
+                    // DTTS_VOC_F16: the stream between a ResBlock's iterations lives in the blocked layout (rb_common.h "BL")
+                    const bool blk = exact && !(h->tune & 128);   // DTTS_TUNE bit 7: row-major everywhere (round 2)
+                    vp.in_blocked = blk && mth > 0;
+                    vp.out_blocked = blk && mth < 2;
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;
@@ -1175,6 +1196,18 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
     // same-box A/B switches for tuning, read ONCE per context (never on the launch path): bit 0 = conv_post as its own kernel,
     // bit 1 = upsamplers without the zero-tap skip, bit 3 = no whole-ResBlock fusion at C >= 128, bit 5 = 128-row tiles for the narrow split-operand upsamplers
     h->tune = getenv("DTTS_TUNE") ? atoi(getenv("DTTS_TUNE")) : 0;
+    {   // prior-sample seed: different per context, process, device and start time (data-parallel ranks and restarts must not draw the
+        // same z_p sequence); dtts_set_noise_seed makes it reproducible
+        static unsigned long long instance = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        unsigned long long z = (unsigned long long)time(nullptr) * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)getpid() << 32) ^
+                               ((unsigned long long)dev << 20) ^ ++instance;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h->noise_seed = z ^ (z >> 31);
+    }
+    h->guard_on = cfg->vocoder_range_guard != 0;
     *out = h;
     return DTTS_OK;
 }
@@ -1382,6 +1415,8 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
     if (c.vocoder_precision != DTTS_VOC_BF16X3) {
         // the fused kernels' persistent workgroups keep a per-utterance tile table (12 B per utterance) in LDS beside their tiles
         if (B > DTTS_MAX_VOCODER_BATCH) return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: B = %d exceeds %d utterances per call", B, DTTS_MAX_VOCODER_BATCH);
+        if (c.vocoder_precision == DTTS_VOC_F16 && ((uintptr_t)mel & 15))
+            return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: DTTS_VOC_F16 reads mel with 16-byte loads: the pointer must be 16-byte aligned");
         return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
     }
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
@@ -1545,8 +1580,11 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         ConvParams p = base_params(enc1, C, B, T_w, T_w, q, C);
         p.out_mul = (float)std::pow((double)D, -0.5);  // q * key_depth_per_head ** -0.5 (dict_encoder.py:45-46)
         LAUNCH(conv1d_launch(h->s2_q, p, s));
-        p = base_params(q, C, B, T_w, T_w, qk, D);
-        LAUNCH(conv1d_launch(h->s2_kT, p, s));
+        const bool projected = entry_ids && h->t_projected;   // resident table of projected rows: logits = K . q, context = Wo sum_l w_l V_l
+        if (!projected) {
+            p = base_params(q, C, B, T_w, T_w, qk, D);
+            LAUNCH(conv1d_launch(h->s2_kT, p, s));
+        }
         if (entry_ids) LAUNCH(max_entry_pm_launch(entry_ids, h->t_pmmax, (long long)rows, pm_max, s));
         else LAUNCH(max_i64_launch(pinyin_map, (long long)rows * P, pm_max, s));
         S2paArgs a;
@@ -1559,7 +1597,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         a.t_poff = h->t_poff;
         a.t_pinyin = h->t_pinyin;
         a.t_pinyin_map = h->t_pinyin_map;
-        a.qk = qk;
+        a.qk = projected ? q : qk;
         a.keys = keys;
         a.values = values;
         a.key_map = key_map;
@@ -1569,7 +1607,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         a.pinyin_emb = h->pinyin_emb;
         a.pm_max = pm_max;
         a.lens = h->lens;
-        a.wv = wv;
+        a.wv = projected ? v : wv;
         a.dict_attn = h->dict_attn;
         a.pron_attn = h->pron_attn;
         a.pron = pron;
@@ -1577,7 +1615,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
         a.T_w = T_w;
         a.L_k = L_k;
         a.P = P;
-        a.D = D;
+        a.D = projected ? C : D;
         a.H = C;
         a.n_pinyin = c.value_embedding_size;
         a.language_zh = c.language_zh;
@@ -1585,8 +1623,10 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
             Timed tm(h, DTTS_TIMER_S2PA, s);
             LAUNCH(s2pa_launch(a, s));
         }
-        p = base_params(wv, D, B, T_w, T_w, v, C);
-        LAUNCH(conv1d_launch(h->s2_v, p, s));
+        if (!projected) {
+            p = base_params(wv, D, B, T_w, T_w, v, C);
+            LAUNCH(conv1d_launch(h->s2_v, p, s));
+        }
         p = base_params(v, C, B, T_w, T_w, h->context, C);
         p.out_lens = h->lens;
         p.zero_masked = 1;  // context * x_mask (dict_encoder.py:140)
@@ -1704,8 +1744,35 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
     h->t_off = (int*)up(tok_off, sizeof(int) * (n_entries + 1));
     h->t_poff = (int*)up(pin_off, sizeof(int) * (n_entries + 1));
     h->t_pmmax = (int*)up(pmmax.data(), sizeof(int) * n_entries);
-    h->t_keys = (float*)up(keys, nL * D * sizeof(float));
-    h->t_values = values ? (float*)up(values, nL * D * sizeof(float)) : h->t_keys;  // the reference stores key == value
+    // SURVEY 8d "resident-table path": the table holds the PROJECTED rows K = k_transform(key), V = v_transform(value)
+    // (dict_encoder.py:36-39: the reference projects every gloss row of every batch; here once, at upload) — 2 x hidden_size floats per
+    // row instead of 768 (+ 768), and the logit becomes k . q in the reference's own association order.  DTTS_TUNE bit 64 keeps the raw
+    // rows (round 2's table: the re-associated kernel of the tensor API reads them).
+    h->t_projected = !(h->tune & 64);
+    if (h->t_projected) {
+        if (!h->acoustic_ready) return fail(h, DTTS_E_STATE, "dtts_dict_table_upload: the acoustic weights must be finalized first (the table stores k_transform / v_transform projections)");
+        const int C = h->cfg.hidden_size;
+        if (nL > (size_t)INT_MAX / 2) return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: %zu gloss rows", nL);
+        float* raw = nullptr;
+        auto proj = [&](const float* src, const PackedConv& L) -> float* {   // [nL][D] host rows -> [nL][C] device rows
+            float* out = nullptr;
+            if (hipMalloc((void**)&out, std::max<size_t>(nL * C * sizeof(float), 16)) != hipSuccess) return nullptr;
+            h->allocs.push_back(out);
+            if (nL == 0) return out;
+            if (hipMemcpy(raw, src, nL * D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+            ConvParams p = base_params(raw, D, 1, (int)nL, (int)nL, out, C);
+            if (conv1d_launch(L, p, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+            return out;
+        };
+        if (hipMalloc((void**)&raw, std::max<size_t>(nL * D * sizeof(float), 16)) != hipSuccess)
+            return fail(h, DTTS_E_NOMEM, "dtts_dict_table_upload: staging buffer for %zu gloss rows", nL);
+        h->t_keys = proj(keys, h->s2_k);
+        h->t_values = proj(values ? values : keys, h->s2_v);
+        (void)hipFree(raw);
+    } else {
+        h->t_keys = (float*)up(keys, nL * D * sizeof(float));
+        h->t_values = values ? (float*)up(values, nL * D * sizeof(float)) : h->t_keys;  // the reference stores key == value
+    }
     h->t_key_map = (float*)up(key_map, nL * sizeof(float));
     h->t_pinyin = (int64_t*)up(pinyin, nP * sizeof(int64_t));
     h->t_pinyin_map = (int64_t*)up(pinyin_map, nP * sizeof(int64_t));
@@ -1753,7 +1820,7 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
         if (z_ld && z_ld < T4) return fail(h, DTTS_E_INVAL, "prior sample holds %d steps per row, T_mel/4 = %d", z_ld, T4);
         LAUNCH(transpose_cf_to_cl_launch(z_p, z, B, Z, T4, s, z_ld));
     } else {
-        LAUNCH(normal_fill_launch(z, (long long)qrows * Z, ++h->noise_counter, s));   // z_p ~ N(0,1) (fvae_semantics.py:110-111)
+        LAUNCH(normal_fill_launch(z, (long long)qrows * Z, h->noise_seed + ++h->noise_counter, s));   // z_p ~ N(0,1) (fvae_semantics.py:110-111)
     }
     // A9: prior flow, reverse
     if (h->fs_w) {   // every block in one kernel (flowstack.hip); the conditioning of all blocks by one convolution
@@ -1923,6 +1990,32 @@ int dtts_length_regulate(dtts_handle h, const float* dur, const int32_t* ilens, 
     }
     (void)hipFree(starts);
     return rc;
+}
+
+int dtts_set_noise_seed(dtts_handle h, uint64_t seed) {
+    if (!h) return DTTS_E_INVAL;
+    h->noise_seed = seed;
+    h->noise_counter = 0x5EEDull;
+    return DTTS_OK;
+}
+
+int dtts_vocoder_range_guard(dtts_handle h, int enable) {
+    if (!h) return DTTS_E_INVAL;
+    if (enable && h->cfg.vocoder_precision != DTTS_VOC_F16) return fail(h, DTTS_E_INVAL, "the range guard exists for DTTS_VOC_F16 only (the other modes have fp32's exponent range)");
+    h->guard_on = enable != 0;
+    return DTTS_OK;
+}
+
+int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream stream) {
+    if (!h || !count) return DTTS_E_INVAL;
+    if (!h->ovf_dev) return fail(h, DTTS_E_STATE, "vocoder weights not finalized");
+    unsigned long long v = 0;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(&v, h->ovf_dev, sizeof v, hipMemcpyDeviceToHost, s));
+    if (reset) HIPCHK(hipMemsetAsync(h->ovf_dev, 0, sizeof v, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *count = (int64_t)v;
+    return DTTS_OK;
 }
 
 int dtts_timer_enable(dtts_handle h, int which) {

@@ -253,7 +253,10 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
     size_t lds = (size_t)rows * (FULL ? p.C_in_pad * ES + 16 : PITCH) * (ENGINE == ENG_BF16X3 ? 2 : 1);
     auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK, FULL>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
+    int cur_dev = 0;
+    if (lds > 65536) (void)hipGetDevice(&cur_dev);
+    size_t& configured = configured_dev[cur_dev & 63];
     if (lds > 65536 && lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -429,7 +429,11 @@ hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream) {
     if (RC < 32 || p.Z != 2 * FS_HALF || p.z_in == p.z_out) return hipErrorInvalidValue;
     if (p.T4 <= 0 || p.B <= 0) return hipSuccess;
     const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST + (size_t)W * FS_HALF) * sizeof(float);
-    static bool configured = false;
+    // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
+    static bool configured_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& configured = configured_dev[cur_dev & 63];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)flowstack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flowstack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -492,9 +492,12 @@ __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, con
 // the main kernel drops from 85 to 67 us but the merge pass costs 10 us plus a launch gap, and merging inside the kernel
 // by the chunk that arrives last needs device-scope fences that write back / invalidate a whole L2 on this multi-XCD
 // part - 235 us.  Net zero by the stream's clock, so the simple form stays.)
+// DM4: float4 pieces of a row per lane (3: the 768-wide gloss embeddings; 1: rows <= 256 wide = the PRE-PROJECTED table, K = key Wk^T /
+// V = value Wv^T, 192 wide); RU: 2 x the rows of a chunk (a wave keeps RU / 2 key rows + RU / 2 value rows, or RU aliased rows, in flight).
+template <int DM4, int RU>
 __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     __shared__ S2paShared sh;
-    constexpr int RU = S2PA_RU;
+    constexpr int S2PA_DMAX4 = DM4;   // (shadows the namespace constant: every per-lane row array below has DM4 pieces)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;  // b * T_w + t
     const int b = row / a.T_w, t = row % a.T_w;
@@ -673,7 +676,8 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
 
 hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
     if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(s2pa_kernel, dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
+    if (a.D <= 256) hipLaunchKernelGGL((s2pa_kernel<1, 8>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
+    else hipLaunchKernelGGL((s2pa_kernel<S2PA_DMAX4, S2PA_RU>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
     return hipGetLastError();
 }
 

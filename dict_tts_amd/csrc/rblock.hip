@@ -19,7 +19,7 @@
 
 namespace dtts {
 
-template <int C, int MT, int NT, int WT, int WC, int EL, int PS>
+template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD>
 __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void rblock_kernel(const RBlockParams p) {
     static_assert(WC * NT * 32 == C, "channel tiling must cover C");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(bias + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     };
     const bool all_inb = base_t >= 0 && base_t + W <= len;   // block-uniform: no row of the tile needs masking
+    int n_ovf = 0;
     auto write_act = [&](const f32x16 (&v)[MT][NT]) {
         if (DTTS_DBG(p, 8)) return;
 #pragma unroll
@@ -203,7 +204,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    uint2 pk = act4<EL>(f32x4{v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]}, 0.1f);
+                    const f32x4 v4 = {v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]};
+                    uint2 pk = act4<EL>(v4, 0.1f);
+                    if constexpr (GUARD) n_ovf += inb ? ovf4(v4, 0.1f) : 0;
                     if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
@@ -355,6 +358,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         }
     }
     }   // (epilogue)
+    if constexpr (GUARD) {
+        if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);   // (halo rows are counted by every tile that recomputes them: a count, not a census)
+    }
     if (!has_next) break;
     if (p.wav) __syncthreads();   // the output tile aliases the activation buffer the next tile is about to write
     j = jn;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }   // (tiles of this workgroup)
 }
 
-template <int C, int MT, int NT, int WT, int WC, int EL, int PS>
+template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD = false>
 static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
     const int H = 6 * (p.K - 1), TT = W - 2 * H;
@@ -380,8 +386,15 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     q.pre_off = (int)lds;                          // tile table: prefix sums [B + 1], counts [B], lengths [B]
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = rblock_kernel<C, MT, NT, WT, WC, EL, PS>;
-    static bool configured = false;
+    if constexpr (EL == EL_F16 && !GUARD) {
+        if (p.ovf) return rb_launch_cfg<C, MT, NT, WT, WC, EL, PS, true>(p, stream);
+    }
+    auto kern = rblock_kernel<C, MT, NT, WT, WC, EL, PS, GUARD>;
+    // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
+    static bool configured_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& configured = configured_dev[cur_dev & 63];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -393,11 +406,11 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
         return hipGetLastError();
     }
     // persistent workgroups: as many as are resident at once (LDS / thread limits), never more than there can be tiles
-    static int cus = 0;
+    static int cus_dev[64] = {};
+    int& cus = cus_dev[cur_dev & 63];
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        if (hipGetDeviceProperties(&prop, cur_dev) != hipSuccess) return hipErrorInvalidDevice;
         cus = prop.multiProcessorCount;
     }
     const int per_cu = std::max(1, std::min({(int)(160 * 1024 / lds), 2048 / THREADS, THREADS <= 256 ? 2 : 1}));

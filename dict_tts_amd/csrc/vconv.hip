@@ -365,7 +365,10 @@ static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
     const size_t ep = (size_t)WT * 32 * (CO_T * 4 + 16);
     if (ep > lds) lds = ep;
     auto kern = vconv_kernel<MT, NT, WT, WC, CK, X3>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
+    int cur_dev = 0;
+    if (lds > 65536) (void)hipGetDevice(&cur_dev);
+    size_t& configured = configured_dev[cur_dev & 63];
     if (lds > 65536 && lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

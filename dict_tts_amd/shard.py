@@ -29,15 +29,39 @@ def n_steps(n_items, world, max_sentences=60):
     return (n_items + step - 1) // step
 
 
+def group_device(dist, group=None):
+    """the device collectives of this process group run on: the current CUDA device for nccl (= RCCL on ROCm), the CPU otherwise"""
+    backend = str(dist.get_backend(group)).lower()
+    if "nccl" in backend:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def ranks_seen(dist, group=None, device_index=None, device_uuid=""):
+    """All-gather of (rank, device index, device uuid) so that a multi-GPU run can prove the collective backend saw `world`
+    DISTINCT devices.  -> list of dicts, one per rank (the uuid travels as 32 bytes)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = group_device(dist, group)
+    if device_index is None:
+        device_index = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    raw = str(device_uuid).encode()[:32].ljust(32, b"\0")
+    rec = torch.tensor([rank, device_index] + list(raw), dtype=torch.int32, device=dev)
+    out = torch.empty(world * rec.numel(), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    rows = out.view(world, -1).cpu().tolist()
+    return [{"rank": r[0], "device_index": r[1], "device_uuid": bytes(r[2:]).rstrip(b"\0").decode(errors="replace")} for r in rows]
+
+
 def gather_mels(mel, lens, dist, group=None, n_mel=80, comm_device=None):
     """All-gather of one step's mels with ragged B and T_mel per rank.
     mel [B,T,n_mel] f32 / lens [B] i32, or (None, None) on a rank that has no batch in this step.
     -> (mel_all [world, B_max, T_max, n_mel], lens_all [world, B_max] (0 = no utterance), meta [world, 2] = (B, T) per rank),
     or (None, None, meta) when no rank has a batch.  Two collectives: the 2-int shape exchange, then the padded gather.
-    comm_device: where the collective runs (default: the tensors' device; pass 'cpu' for a gloo group fed CUDA tensors)."""
+    comm_device: where the collective runs; default = the device the process group's backend needs (``group_device``: the current
+    CUDA device for nccl/RCCL, the CPU for gloo) — NOT the mel's device, so that a rank without a batch enters the collectives with
+    tensors on the same kind of device as every other rank."""
     world = dist.get_world_size(group)
-    src_dev = mel.device if mel is not None else torch.device("cpu")
-    dev = torch.device(comm_device) if comm_device is not None else src_dev
+    dev = torch.device(comm_device) if comm_device is not None else group_device(dist, group)
     B, T = (int(mel.shape[0]), int(mel.shape[1])) if mel is not None else (0, 0)
     meta = torch.tensor([B, T], dtype=torch.int32, device=dev)
     meta_all = torch.empty(world * 2, dtype=torch.int32, device=dev)   # outputs are the dim-0 concatenation (gloo insists on it)

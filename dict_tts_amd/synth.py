@@ -162,9 +162,9 @@ def hifigan_config():
             "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]]}
 
 
-def hifigan_state_dict(seed=1234, weight_norm=True):
+def hifigan_state_dict(seed=1234, weight_norm=True, cfg=None):
     """numpy state dict of ``HifiGanGenerator`` (``state_dict.model_gen``), weight-norm form by default."""
-    cfg = hifigan_config()
+    cfg = cfg or hifigan_config()
     sd = {}
     c0 = cfg["upsample_initial_channel"]
     _conv(sd, seed, "conv_pre", c0, N_MEL, 7, gain=0.35, wn=weight_norm)

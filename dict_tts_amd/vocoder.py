@@ -61,7 +61,15 @@ def find_vocoder_checkpoint(base_dir):
 class HifiGAN:
     """Same contract as the reference class: ``spec2wav(mel[T,80], **ignored) -> np.float32[T*hop]``."""
 
-    def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False):
+    GUARD_CALLS = 4   # precision not chosen explicitly: the first calls run with the fp16 range guard on
+
+    def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False, range_guard=None):
+        """precision: None (= env DTTS_VOCODER_PRECISION, else AUTO) | 'f16' | 'bf16' | 'bf16x3' | abi.VOC_*.
+        AUTO = DTTS_VOC_F16 (the waveform-exact default) with two safety nets, because fp16 operands have a narrower range than
+        the reference's fp32 arithmetic: (1) a generator shape the fused fp16 kernels do not cover falls back to DTTS_VOC_BF16X3
+        at construction; (2) the first GUARD_CALLS forward calls run with the library's range guard on (dtts_vocoder_range_guard)
+        and a call that saturated / overflowed an fp16 activation is REDONE in DTTS_VOC_BF16X3, which the object then keeps.
+        An explicit precision is taken literally; range_guard=True then keeps the guard on for every call and raises on a clamp."""
         if state_dict is None:
             config, state_dict = find_vocoder_checkpoint(hparams_mod.hparams["vocoder_ckpt"])   # looked up at call time: the
             # INTEGRATION.md hook may rebind dict_tts_amd.hparams.hparams after this module was imported
@@ -69,19 +77,47 @@ class HifiGAN:
         if not torch.cuda.is_available():
             raise abi.DttsError("dict_tts_amd.vocoder.HifiGAN needs a ROCm GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
-        if precision is None:
-            precision = abi.VOC_PRECISIONS[os.environ.get("DTTS_VOCODER_PRECISION", "f16")]   # f16 = the waveform-exact default
+        if precision is None and os.environ.get("DTTS_VOCODER_PRECISION"):
+            precision = os.environ["DTTS_VOCODER_PRECISION"]
+        auto = precision is None
+        if auto:
+            precision = abi.VOC_F16   # the waveform-exact default
         elif isinstance(precision, str):
             precision = abi.VOC_PRECISIONS[precision]
-        self.precision = precision
-        if ctx is None:
-            cfg = fill_abi_config(abi.default_config(), None, self.config, vocoder_precision=precision)
-            cfg.vocoder_unfused = 1 if unfused else 0   # testing aid (bf16 mode): one kernel per convolution
-            ctx = abi.Context(cfg)
-        self.ctx = ctx
-        self.ctx.load_state_dict("vocoder", state_dict)
-        self.ctx.finalize(abi.PART_VOCODER)
+        self._unfused = unfused
+        self._guard_left = 0
+        self._guard_raise = False
+        self._state_dict = None
+        if ctx is not None:
+            self.precision = precision
+            self.ctx = ctx
+            self.ctx.load_state_dict("vocoder", state_dict)
+            self.ctx.finalize(abi.PART_VOCODER)
+        else:
+            guard = precision == abi.VOC_F16 and (auto or bool(range_guard))
+            try:
+                self._build(state_dict, precision, guard)
+            except abi.DttsError as e:
+                if not (auto and "DTTS_VOC_BF16X3" in str(e)):
+                    raise
+                import warnings
+                warnings.warn(f"HifiGAN: the fused fp16 kernels do not cover this generator ({e}); using DTTS_VOC_BF16X3")
+                self._build(state_dict, abi.VOC_BF16X3, False)
+                guard = False
+            if guard:
+                self._guard_left = -1 if range_guard else self.GUARD_CALLS
+                self._guard_raise = bool(range_guard) and not auto
+                self._state_dict = state_dict if auto else None   # kept until the guarded calls are over (needed for the fallback)
         self.hop = self.ctx.hop()
+
+    def _build(self, state_dict, precision, guard):
+        cfg = fill_abi_config(abi.default_config(), None, self.config, vocoder_precision=precision)
+        cfg.vocoder_unfused = 1 if self._unfused else 0   # testing aid (bf16 mode): one kernel per convolution
+        cfg.vocoder_range_guard = 1 if guard else 0
+        ctx = abi.Context(cfg)
+        ctx.load_state_dict("vocoder", state_dict)
+        ctx.finalize(abi.PART_VOCODER)
+        self.ctx, self.precision = ctx, precision
 
     # -- reference API -------------------------------------------------------------------------------------
     def spec2wav(self, mel, **kwargs):
@@ -98,8 +134,25 @@ class HifiGAN:
         wav = torch.empty(B, T * self.hop, dtype=torch.float32, device=mel.device)
         if lens is not None:
             lens = lens.to(device=mel.device, dtype=torch.int32).contiguous()
-        self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
+        if self._guard_left:
+            n = self.ctx.vocoder_clamped(stream)   # (synchronises the stream: only during the guarded calls)
+            if n:
+                if self._guard_raise or self._state_dict is None:
+                    raise abi.DttsError(f"DTTS_VOC_F16: {n} activations exceeded the fp16 range (the reference computes in fp32, "
+                                        f"modules/hifigan/hifigan.py:51-58); use precision='bf16x3'")
+                import warnings
+                warnings.warn(f"HifiGAN: {n} activations exceeded the fp16 range; switching to DTTS_VOC_BF16X3 and redoing this call")
+                self._guard_left = 0
+                self._build(self._state_dict, abi.VOC_BF16X3, False)
+                self._state_dict = None
+                self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
+            elif self._guard_left > 0:
+                self._guard_left -= 1
+                if self._guard_left == 0:
+                    self.ctx.vocoder_range_guard(False)
+                    self._state_dict = None
         return wav
 
     def to_int16(self, wav, lens=None, norm=False):

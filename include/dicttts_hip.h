@@ -95,6 +95,7 @@ typedef struct dtts_config {
     int32_t fft_use_last_norm;        /* FFTBlocks(use_last_norm=True)                                        */
     int32_t vocoder_unfused;          /* testing aid, DTTS_VOC_BF16 only: 1 = one kernel per convolution instead of the fused ResBlock kernels */
     int32_t decoder_fp32;             /* 1 = FVAE decoder WaveNet on exact fp32 MFMA (round 1); 0 (default) = bf16 hi/lo split operands */
+    int32_t vocoder_range_guard;      /* DTTS_VOC_F16: 1 = start with the fp16 range guard on (dtts_vocoder_range_guard) */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
@@ -145,6 +146,11 @@ int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const fl
  * ~1.5 GB at B=60.  Uploaded once, the ragged table (one entry per dictionary word: gloss embeddings [L_e,768],
  * key_map [L_e], pinyin / pinyin_map [P_e]; items of data_gen/tts/binarizer_zh.py:301-309) stays in HBM and a batch
  * carries only ids.  All pointers are HOST pointers; values may be NULL (the reference stores value == key).
+ * What stays resident is the PROJECTED table: K = k_transform(key), V = v_transform(value), hidden_size floats per row each
+ * (modules/dict_tts/layers/dict_encoder.py:36-39 projects every gloss row of every batch; here once, on the device, at upload):
+ * 2 * hidden_size * 4 = 1,536 B per gloss row instead of 3,072 (6,144 with separate values), and the id path computes
+ * logits = K . q and context = Wo sum_l w_l V_l in the reference's own association order.  Consequences: the acoustic weights
+ * must be finalized BEFORE this call (DTTS_E_STATE otherwise), and re-loading them requires a new upload.
  */
 int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off_host, const float* keys_host,
                            const float* values_host, const float* key_map_host, const int32_t* pin_off_host,
@@ -245,6 +251,19 @@ int dtts_fft_blocks_forward(dtts_handle h, const float* x_dev, const int32_t* le
  */
 int dtts_wav_to_int16(dtts_handle h, const float* wav_dev, const int32_t* lens_dev, int B, int T, int norm, int16_t* out_dev,
                       dtts_stream stream);
+
+/* Seed of the device-side prior sample (z_p == NULL in dtts_text2mel_decode / _forward*).  Every context starts from a seed mixed from
+ * the time, the process id, the device and a per-process instance count, so that data-parallel ranks and restarts draw different
+ * noise (the reference draws from torch's global RNG, modules/dict_tts/fvae_semantics.py:110-111); setting it makes a run repeatable. */
+int dtts_set_noise_seed(dtts_handle h, uint64_t seed);
+
+/* fp16 range guard (DTTS_VOC_F16).  The ResBlock convolutions round their activations to fp16: leaky_relu(v) > 65504 saturates and
+ * v * 0.1 < -65504 overflows, where the reference computes in fp32 (modules/hifigan/hifigan.py:51-58).  While the guard is on, the
+ * fused ResBlock kernels run an instantiation that COUNTS such activations (a few % slower); dtts_vocoder_clamped returns the count
+ * accumulated since the last reset (it synchronises `stream`).  A non-zero count means this mode is not valid for the checkpoint /
+ * input at hand: use DTTS_VOC_BF16X3 (dict_tts_amd/vocoder.py does that automatically when the precision was not chosen explicitly). */
+int dtts_vocoder_range_guard(dtts_handle h, int enable);
+int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream stream);
 
 /*
  * Instrumentation used by bench.py: accumulated device time (hipEvent pairs recorded on the caller's stream

@@ -265,17 +265,16 @@ def test_hifigan_many_utterances_persistent_tiles(voc, oracle_voc_sd):
 
 
 def test_hifigan_linearity_free_properties_long(voc):
-    voc_bf16 = voc
     """size-independent properties at a realistic length (400 frames): determinism, finite output in (-1, 1),
     and shift-consistency — the middle of the utterance does not depend on what is 200 frames away"""
     mel = synth.random_mel(5, 400, "long")
-    a = voc_bf16.spec2wav(mel)
-    b = voc_bf16.spec2wav(mel)
+    a = voc.spec2wav(mel)
+    b = voc.spec2wav(mel)
     assert np.array_equal(a, b)
     assert np.isfinite(a).all() and np.abs(a).max() < 1.0
     mel2 = mel.copy()
     mel2[:100] = synth.random_mel(6, 100, "other")
-    c = voc_bf16.spec2wav(mel2)
+    c = voc.spec2wav(mel2)
     mid = slice(300 * 256, 350 * 256)   # > receptive field away from the edited frames
     assert np.array_equal(a[mid], c[mid])
 
@@ -367,8 +366,8 @@ def test_config5_dictionary_stress_mixed_lengths(acoustic, oracle_sd):
 # ------------------------------------------------------------------------------------------------ resident dictionary
 def test_resident_dictionary_ids_equal_collated_tensors(acoustic):
     """dtts_dict_table_upload + dtts_text2mel_encode_ids (batches carry only ids) must reproduce
-    dtts_text2mel_encode on the tensors DictTTSDataset.collater would build from the same table — bit for bit, since
-    the same kernels read the same numbers: ragged lengths, heteronyms, forced senses, an UNK (zero) entry."""
+    dtts_text2mel_encode on the tensors DictTTSDataset.collater would build from the same table: ragged lengths, heteronyms,
+    forced senses, an UNK (zero) entry."""
     st = synth.biaobei_struct()
     entries = dict(st["entries"])
     unk = 7000
@@ -384,8 +383,12 @@ def test_resident_dictionary_ids_equal_collated_tensors(acoustic):
                   (T(tb["keys"]), T(tb["values"]), T(tb["key_map"]), T(tb["pinyin"]), T(tb["pinyin_map"])), infer=True)
     zp = ra["z_p_in"]
     rb = acoustic.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"], z_p=zp)
-    for k in ("mel2word", "dur", "pron_attn", "dict_attn", "word_encoder_out", "mel_out"):
-        assert torch.equal(ra[k], rb[k]), k
+    # round 3: the resident table holds the PROJECTED rows (K = key Wk^T, V = value Wv^T), so the id path computes k . q in the
+    # reference's association order while the tensor API keeps the re-associated key . (Wk^T q): the same numbers up to fp32
+    # rounding, no longer bit for bit — both within the oracle tolerances of each other, integer durations identical
+    assert torch.equal(ra["mel2word"], rb["mel2word"])
+    for k, tol in (("dur", 1e-5), ("pron_attn", 1e-5), ("dict_attn", 1e-5), ("word_encoder_out", 1e-4), ("mel_out", 1e-3)):
+        assert (ra[k] - rb[k]).abs().max() <= tol, (k, float((ra[k] - rb[k]).abs().max()))
     ctx = abi.Context()
     with pytest.raises(abi.DttsError, match="not finalized|before dtts_dict_table_upload"):
         ctx.text2mel_encode_ids(1, 1, None, None, 1, 4, 8, 2, None)
@@ -393,7 +396,6 @@ def test_resident_dictionary_ids_equal_collated_tensors(acoustic):
 
 @pytest.mark.gpu
 def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc, tmp_path):
-    voc_bf16 = voc
     """run_inference(pipeline=True) overlaps the vocoder of batch i with text->mel of batch i+1 on two streams; the
     files it writes must be byte-identical to the serial loop's (same kernels, same inputs, buffers never shared)"""
     from scipy.io import wavfile
@@ -411,7 +413,7 @@ def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc, tmp_path
     for mode in (False, True):
         torch.manual_seed(7)                            # z_p is drawn from the CPU generator, in batch order
         d = tmp_path / ("pipe" if mode else "serial")
-        rows = infer.run_inference(acoustic, voc_bf16, batches, str(d), enc, pipeline=mode)
+        rows = infer.run_inference(acoustic, voc, batches, str(d), enc, pipeline=mode)
         assert len(rows) == 10
         out[mode] = (rows, [wavfile.read(os.path.join(d, "wavs", r["wav_fn_pred"] + ".wav"))[1] for r in rows])
     assert out[False][0] == out[True][0]
@@ -422,18 +424,17 @@ def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc, tmp_path
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm", [False, True])
 def test_device_int16_conversion_equals_reference_rule(voc, norm):
-    voc_bf16 = voc
     """dtts_wav_to_int16 == utils/audio.py:11-16 per utterance over its own valid samples (wav / max|wav| if norm;
     * 32767 in fp32; truncating astype(int16)), bit for bit; samples past an utterance's end are 0"""
     from dict_tts_amd import infer
-    hop = voc_bf16.hop
+    hop = voc.hop
     rng = np.random.default_rng(5)
     lens = np.array([7, 3, 0, 5], np.int32)
     wav = rng.uniform(-1, 1, (4, 7 * hop)).astype(np.float32)
     wav[0, :6] = [0.0, 0.5, -0.5, 0.99997, -1.0, 1.0]
     wav[1] *= 0.01                                        # quiet utterance: norm matters
     wav[1, 3 * hop:] = 0.9                                # beyond its end: must not enter its max
-    got = voc_bf16.to_int16(T(wav).cuda(), T(lens).cuda(), norm=norm).cpu().numpy()
+    got = voc.to_int16(T(wav).cuda(), T(lens).cuda(), norm=norm).cpu().numpy()
     assert got.dtype == np.int16 and got.shape == wav.shape
     for b in range(4):
         n = int(lens[b]) * hop
@@ -495,7 +496,10 @@ def test_config2_batch60_full_size_vs_oracle(acoustic, oracle_sd, voc, oracle_vo
     tie = ((v - v.floor() - 0.5).abs() < 5e-5) & (b["word_tokens"] > 0)
     gi = (got["dur"].cpu().exp() - 1).round().clamp(min=0)
     wi = v.round().clamp(min=0)
-    assert int(tie.sum()) <= 2 and torch.equal(gi[~tie], wi[~tie]), (int(tie.sum()), int((gi != wi).sum()))
+    n_ties, n_flips = int(tie.sum()), int((gi != wi).sum())
+    print(f"\n[config2 B=60] words {int((b['word_tokens'] > 0).sum())}  n_ties (|frac - .5| < 5e-5 in the oracle) {n_ties}  "
+          f"n_flips (integer durations that differ from the oracle's) {n_flips}  flips outside ties {int(((gi != wi) & ~tie).sum())}")
+    assert n_ties <= 2 and torch.equal(gi[~tie], wi[~tie]), (n_ties, n_flips)
     if not torch.equal(got["mel2word"].cpu(), want["mel2word"]):   # a tie went the other way: compare the rest on the SAME durations
         assert bool(((gi != wi) & ~tie).sum() == 0)
         want = ref.forward_infer(oracle_sd, b["word_tokens"], dm, b["pron_modified"], mel2word=got["mel2word"].cpu(),
@@ -560,6 +564,63 @@ def test_b1_waveform_covers_the_padded_frames(acoustic, oracle_sd, voc, oracle_v
         assert rms(d) <= 1e-4 * 32767 + 0.5 and np.abs(d).max() <= 40, (rms(d), np.abs(d).max())   # the waveform gate in int16 LSBs (+ truncation)
         break
     assert hit, "none of the six sentences needed padding to frames_multiple"
+
+
+def test_g10_reference_written_dict_embed_through_the_id_path_vs_oracle(acoustic, oracle_sd, golden_dir):
+    """VERDICT r2 #7a: the ``dict_embed.{idx,data}`` dataset the REFERENCE's IndexedDatasetBuilder wrote (fixture G10) is read
+    (dict_tts_amd/dict_embed.py), uploaded as the resident table, and dtts_text2mel_encode_ids on word ids is compared with the
+    ORACLE on the tensors the reference's collater builds from the same four items: per sentence get_dict_embeddings
+    (tasks/tts/dataset_utils.py:305-330: collate_2d / collate_1d over the words, pad 0), per batch collater (:285-297: collate_3d,
+    then one row in front / behind along T_w filled with 0 for keys / values / pinyin and 1 for key_map / pinyin_map)."""
+    from dict_tts_amd import dict_embed
+    from dict_tts_amd.model import decode_pinyin_ids
+    from oracle import dict_tts_ref as ref
+    base = os.path.join(golden_dir, "g10_dict_embed")
+    table = dict_embed.table_from_dict_embed(base, os.path.join(golden_dir, "g10_pinyin_encoder.pkl"))
+    items = dict_embed.read_indexed_dataset(base)
+    import pickle
+    with open(os.path.join(golden_dir, "g10_pinyin_encoder.pkl"), "rb") as f:
+        penc = pickle.load(f)
+    acoustic.upload_dict_table(table)
+    sents = [[1, 2, 3, 0, 2], [3, 1], [2, 2, 2, 1, 0, 3, 1]]           # word ids = dataset item indices (item 0: the zero entry)
+    B, Tw = len(sents), max(len(s) for s in sents) + 2
+    L_k = max(int(np.asarray(items[w]["key"]).shape[0]) for s in sents for w in s)
+    P = max(len(items[w]["pinyin"]) for s in sents for w in s)
+    keys = np.zeros((B, Tw, L_k, 768), np.float32)
+    key_map = np.zeros((B, Tw, L_k), np.float32)
+    pinyin = np.zeros((B, Tw, P), np.int64)
+    pinyin_map = np.zeros((B, Tw, P), np.int64)
+    word_tokens = np.zeros((B, Tw), np.int64)
+    entry = np.full((B, Tw), -2, np.int32)
+    pron_modified = np.zeros((B, Tw), np.int64)
+    for b, sen in enumerate(sents):
+        word_tokens[b, :len(sen) + 2] = [synth.BOS_ID] + [10 + w for w in sen] + [synth.EOS_ID]
+        for t, w in enumerate(sen):
+            it = items[w]
+            k = np.asarray(it["key"], np.float32)
+            keys[b, t + 1, :k.shape[0]] = k
+            key_map[b, t + 1, :k.shape[0]] = it["key_map"]
+            pinyin[b, t + 1, :len(it["pinyin"])] = [penc.index(x) for x in it["pinyin"]]     # dataset_utils.py:322
+            pinyin_map[b, t + 1, :len(it["pinyin"])] = it["pinyin_map"]
+            entry[b, t + 1] = w
+    key_map[:, 0] = key_map[:, -1] = 1                                   # collater :288-289 (value=1), keys / pinyin rows stay 0
+    pinyin_map[:, 0] = pinyin_map[:, -1] = 1
+    entry[:, 0] = entry[:, -1] = -1
+    pron_modified[0, 2] = 2                                              # the two-sense heteronym forced to its second sense
+    pron_modified[2, 6] = 3                                              # the three-sense one to its third
+    z = lambda B_, T4: T(synth.noise(71, B_, T4))
+    want = ref.forward_infer(oracle_sd, T(word_tokens), (T(keys), T(keys.copy()), T(key_map), T(pinyin), T(pinyin_map)), T(pron_modified), z_p=z)
+    T_mel = want["mel_out"].shape[1]
+    got = acoustic.forward_ids(T(word_tokens), T(entry), T(pron_modified), L_k, P, z_p=z(B, T_mel // 4))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"])
+    assert (got["pron_attn"].cpu() - want["pron_attn"]).abs().max() <= 1e-5
+    assert (got["dict_attn"].cpu() - want["dict_attn"]).abs().max() <= 1e-5
+    assert (got["word_encoder_out"].cpu() - want["word_encoder_out"]).abs().max() <= 1e-4
+    assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+    for u in range(B):
+        assert decode_pinyin_ids(got["pron_attn"][u], pinyin[u]) == ref.decode_pinyin(want["pron_attn"][u], T(pinyin[u]))
+    assert abs(float(got["pron_attn"][0, 2].max()) - 1.0) <= 1e-6        # the forced rows are one-hot over that sense's tokens
+    acoustic.upload_dict_table(synth.dict_table(gc.SEED))               # leave the Biaobei table resident for the other tests
 
 
 def test_config5_full_dictionary_resident_table_vs_oracle(acoustic, oracle_sd):
@@ -814,6 +875,103 @@ def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
         assert torch.equal(got["mel2word"].cpu(), want["mel2word"]), k
         assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-5
         assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
+
+
+def test_fp16_range_guard_fires_and_falls_back(voc_sd, oracle_voc_sd):
+    """fp16 ResBlock operands saturate at 65504 where the reference computes in fp32 (hifigan.py:51-58).  With the
+    first stage's ResBlock weights scaled up the activations leave the fp16 range: the guarded kernels COUNT them
+    (dtts_vocoder_clamped), HifiGAN(precision=None) redoes the call in DTTS_VOC_BF16X3 and keeps that mode, an explicit
+    precision='f16' with range_guard=True raises, and the healthy checkpoint counts zero and stays in fp16."""
+    import warnings
+    from dict_tts_amd import vocoder
+    from oracle import hifigan_ref as href
+    # convs1 of the first stage's k = 3 / k = 7 ResBlocks x300 (the third iteration's activations reach ~1e7), ups.1 x1e-6 brings the
+    # stream back to O(1) so that the waveform is not a saturated tanh and differences stay visible
+    big = {k: (v * 300.0 if (k.startswith("resblocks.0.") or k.startswith("resblocks.1.")) and "convs1" in k and k.endswith("weight_g")
+               else (v * 1e-6 if k == "ups.1.weight_g" else v)) for k, v in voc_sd.items()}
+    mel = synth.random_mel(11, 40, "guard")
+    # healthy weights: zero clamps over the guarded calls, the mode stays fp16 and the guard switches itself off
+    v0 = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config())
+    assert v0.precision == abi.VOC_F16 and v0._guard_left == vocoder.HifiGAN.GUARD_CALLS
+    for _ in range(vocoder.HifiGAN.GUARD_CALLS):
+        v0.spec2wav(mel)
+    assert v0.precision == abi.VOC_F16 and v0._guard_left == 0 and v0._state_dict is None
+    # scaled weights, explicit fp16 without the guard: runs, and returns a clipped / overflowed waveform without a word (what round 2
+    # did for every caller; v * 0.1 < -65504 converts to -inf, so the damage is usually NaN, not a subtle error)
+    v1 = vocoder.HifiGAN(state_dict=big, config=synth.hifigan_config(), precision="f16")
+    w_clip = v1.spec2wav(mel)
+    # the counter, through the C ABI
+    v1.ctx.vocoder_range_guard(True)
+    v1.spec2wav(mel)
+    n = v1.ctx.vocoder_clamped(torch.cuda.current_stream().cuda_stream)
+    assert n > 0 and v1.ctx.vocoder_clamped(torch.cuda.current_stream().cuda_stream) == 0   # (reset by the first read)
+    # explicit fp16 + range_guard=True: raises instead of returning a clipped waveform
+    v2 = vocoder.HifiGAN(state_dict=big, config=synth.hifigan_config(), precision="f16", range_guard=True)
+    with pytest.raises(abi.DttsError, match="exceeded the fp16 range"):
+        v2.spec2wav(mel)
+    # precision not chosen: the call is redone in bf16x3 and equals an explicit bf16x3 vocoder = the fp32-class oracle
+    v3 = vocoder.HifiGAN(state_dict=big, config=synth.hifigan_config())
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        w_auto = v3.spec2wav(mel)
+    assert v3.precision == abi.VOC_BF16X3 and any("fp16 range" in str(w.message) for w in ws)
+    w_x3 = vocoder.HifiGAN(state_dict=big, config=synth.hifigan_config(), precision="bf16x3").spec2wav(mel)
+    assert np.array_equal(w_auto, w_x3)
+    want = href.spec2wav(href.fold_weight_norm(big), synth.hifigan_config(), mel).numpy()
+    assert rms(w_auto - want) <= 1e-4, rms(w_auto - want)
+    assert not np.isfinite(w_clip).all() or rms(w_clip - want) > 1e-3   # the unguarded fp16 result is wrong
+    with pytest.raises(abi.DttsError, match="DTTS_VOC_F16 only"):
+        vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="bf16").ctx.vocoder_range_guard(True)
+
+
+def test_auto_precision_falls_back_for_uncovered_generator_shapes(voc_sd):
+    """a generator whose ResBlock widths the fused fp16 kernels do not cover (upsample_initial_channel = 384 -> 192 / 96 /
+    48 / 24 channels) must still construct when the precision was not chosen explicitly: DTTS_VOC_BF16X3 on the generic kernel;
+    an explicit precision='f16' keeps failing loudly."""
+    import warnings
+    from dict_tts_amd import vocoder
+    from oracle import hifigan_ref as href
+    cfg = dict(synth.hifigan_config(), upsample_initial_channel=384)
+    sd = {k: T(v) for k, v in synth.hifigan_state_dict(gc.SEED, cfg=cfg).items()}
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        v = vocoder.HifiGAN(state_dict=sd, config=cfg)
+    assert v.precision == abi.VOC_BF16X3 and any("do not cover" in str(w.message) for w in ws)
+    mel = synth.random_mel(3, 24, "odd")
+    want = href.spec2wav(href.fold_weight_norm(sd), cfg, mel).numpy()
+    wave_gate(v.spec2wav(mel), want)
+    with pytest.raises(abi.DttsError, match="ResBlock widths"):
+        vocoder.HifiGAN(state_dict=sd, config=cfg, precision="f16")
+
+
+def test_device_prior_sample_seed(acoustic):
+    """the DEVICE-side prior sample (dtts_text2mel_decode with z_p = NULL — what bench.py runs; the Python shim draws z_p
+    from torch's RNG as the reference does) is seeded per context: two contexts draw different noise, the same seed reproduces a
+    run (dtts_set_noise_seed), consecutive calls differ"""
+    from dict_tts_amd import model
+    st = synth.biaobei_struct()
+    b = {k: T(v).cuda() for k, v in synth.make_batch(st["sentences"][:2], gc.SEED).items()}
+    other = model.PortaSpeech_dict(hparams={})
+    other.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()}, strict=True)
+    s = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: t.data_ptr()
+
+    def draw(m):
+        B, T_w = b["word_tokens"].shape
+        T_mel = m.ctx.text2mel_encode(ptr(b["word_tokens"]), ptr(b["keys"]), ptr(b["values"]), ptr(b["key_map"]), ptr(b["pinyin"]),
+                                      ptr(b["pinyin_map"]), ptr(b["pron_modified"]), None, B, T_w, b["keys"].shape[2], b["pinyin"].shape[2], s)
+        mel = torch.empty(B, T_mel, 80, device="cuda")
+        m.ctx.text2mel_decode(None, mel.data_ptr(), s)
+        torch.cuda.synchronize()
+        return mel
+
+    a1, o1 = draw(acoustic), draw(other)
+    assert a1.shape == o1.shape and torch.isfinite(a1).all() and not torch.equal(a1, o1)   # different contexts: different z_p
+    acoustic.ctx.set_noise_seed(77)
+    other.ctx.set_noise_seed(77)
+    a2, a3, o2 = draw(acoustic), draw(acoustic), draw(other)
+    assert torch.equal(a2, o2) and not torch.equal(a2, a3)                                  # same seed: same first draw; calls differ
+
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 control flow on one GPU

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dict_tts_amd.shard import gather_mels, n_steps, shard_indices
+from dict_tts_amd.shard import gather_mels, group_device, n_steps, ranks_seen, shard_indices
 
 
 def test_shard_indices_partition():
@@ -63,6 +63,10 @@ def _worker(rank, world, port, q):
             B, T = wm.shape[:2]
             ok = ok and torch.equal(mel_all[r, :B, :T], wm) and float(mel_all[r, B:].abs().sum()) == 0
             ok = ok and float(mel_all[r, :, T:].abs().sum()) == 0 and lens_all[r, :B].tolist() == wl.tolist()
+    # the collectives' device follows the BACKEND (a rank without a batch must not fall back to a different device kind)
+    ok = ok and group_device(dist) == torch.device("cpu")
+    seen = ranks_seen(dist, device_index=10 + rank, device_uuid=f"GPU-fake-{rank}")
+    ok = ok and seen == [{"rank": r, "device_index": 10 + r, "device_uuid": f"GPU-fake-{r}"} for r in range(world)]
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -81,3 +85,19 @@ def test_gather_mels_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_group_device_follows_backend():
+    """with an nccl (RCCL) group a rank WITHOUT a batch must create its collective buffers on its CUDA device, not the CPU."""
+    class FakeDist:
+        def __init__(self, b):
+            self.b = b
+
+        def get_backend(self, group=None):
+            return self.b
+
+    import unittest.mock as mock
+    with mock.patch("torch.cuda.current_device", return_value=3):
+        assert group_device(FakeDist("nccl")) == torch.device("cuda", 3)
+        assert group_device(FakeDist("cpu:gloo,cuda:nccl")) == torch.device("cuda", 3)
+    assert group_device(FakeDist("gloo")) == torch.device("cpu")
