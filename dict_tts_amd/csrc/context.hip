@@ -475,7 +475,7 @@ int build_acoustic(dtts_ctx* h) {
     h->dur_bias = upload_named(h, need, m + "dur_predictor.linear.0.bias");
     ok = ok && h->dur_w && h->dur_bias;
     // FVAE
-    ok = ok && pack_plain(h, need, h->g_pre, ENG_F32, m + "fvae.g_pre_net.0", 1, 4, 2);
+    ok = ok && pack_plain(h, need, h->g_pre, (c.decoder_fp32 || (h->tune & 1024)) ? ENG_F32 : ENG_BF16X3, m + "fvae.g_pre_net.0", 1, 4, 2);   // DTTS_TUNE bit 10: fp32 (round 2)
     const int half = c.latent_size / 2;
     h->flows.clear();
     int parity = 0;
@@ -549,7 +549,9 @@ int build_acoustic(dtts_ctx* h) {
         h->fs_w = upload(h, fs_host);
         const int n_c = (int)fs_cond_b.size(), Cg = c.hidden_size;
         const float* pc = fs_cond_w.data();
-        ok = ok && h->fs_w && pack_conv(h, h->fs_cond, ENG_F32, n_c, Cg, 1, [=](int co, int ci, int) { return pc[(size_t)co * Cg + ci]; }, fs_cond_b, 1, 1, 0);
+        // (split-bf16 operands on the vconv kernel like the WaveNet layers it conditions, unless the exact-fp32 decoder was asked for)
+        ok = ok && h->fs_w && pack_conv(h, h->fs_cond, (c.decoder_fp32 || Cg % 64 || n_c % 256 || (h->tune & 2048)) ? ENG_F32 : ENG_BF16X3, n_c, Cg, 1,
+                                         [=](int co, int ci, int) { return pc[(size_t)co * Cg + ci]; }, fs_cond_b, 1, 1, 0);
     }
     ok = ok && pack_transposed(h, need, h->dec_pre, ENG_F32, m + "fvae.decoder.pre_net.0", 4, 0);
     // the decoder WaveNet carries 4.09 of the acoustic model's 4.69 MFLOP per frame: split-bf16 operands (three bf16 MFMAs
@@ -903,7 +905,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         for (int i = 0; i < nup; ++i) {
             rows *= c.upsample_rates[i];
             ch /= 2;
-            max_elems = std::max<size_t>(max_elems, (size_t)B * ((rows + 31) & ~(size_t)31) * ch);   // (blocked tensors pad to 32 rows per utterance)
+            max_elems = std::max<size_t>(max_elems, (size_t)B * rows * ch);
         }
     }
     const int melC = h->conv_pre.C_in_pad;
@@ -1046,10 +1048,6 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                         vp.stats = dstats;
                     }
 #endif
-                    // DTTS_VOC_F16: the stream between a ResBlock's iterations lives in the blocked layout (rb_common.h "BL")
-                    const bool blk = exact && !(h->tune & 128);   // DTTS_TUNE bit 7: row-major everywhere (round 2)
-                    vp.in_blocked = blk && mth > 0;
-                    vp.out_blocked = blk && mth < 2;
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;
@@ -1828,8 +1826,15 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
         float* cond_all = A.alloc<float>(qrows * n_c);
         float* z2 = A.alloc<float>(qrows * Z);
         if (!cond_all || !z2) return fail(h, DTTS_E_NOMEM, "decoder workspace");
-        p = base_params(gs, C, B, T4, T4, cond_all, n_c);
-        LAUNCH(conv1d_launch(h->fs_cond, p, s));
+        if (h->fs_cond.engine == ENG_BF16X3) {
+            VConvParams v = vparams_x3(h->fs_cond, gs, C, 1.f, nullptr, B, T4);
+            v.yf = cond_all;
+            v.ldyf = n_c;
+            LAUNCH(vconv_launch(v, s));
+        } else {
+            p = base_params(gs, C, B, T4, T4, cond_all, n_c);
+            LAUNCH(conv1d_launch(h->fs_cond, p, s));
+        }
         FlowStackParams fp;
         memset(&fp, 0, sizeof fp);
         fp.z_in = z;

@@ -92,19 +92,6 @@ __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ---- blocked fp32 layout ("BL") of the vocoder's inter-kernel tensors in DTTS_VOC_F16: per utterance
-//   [row tile t >> 5][co-tile c >> 5][q = (c & 31) >> 3][half = (c >> 2) & 1][r = t & 31][e = c & 3]
-// i.e. a 32-row x 32-channel block (4 KB) is stored in the MFMA accumulator layout of D[co][t] (lane = 32 half + r holds the four
-// channels 8q + 4half + e of row r in registers 4q .. 4q+3): a wave's 16-byte-per-lane access to one accumulator quad is 1 KB
-// contiguous, so the kernels load the residual stream straight INTO accumulators and store results straight FROM them — no LDS
-// transposition, no barriers, no staging buffer — and a row-tile that starts at any t (not a multiple of 32) costs two 512-byte runs
-// per half instead of one 1 KB run.  Rows are padded to a multiple of 32 per utterance (bl_rows); rows outside [0, len) are never
-// read (the offset is sent out of range, the buffer load returns 0 = the reference's zero padding) and never written.
-__device__ __forceinline__ int bl_rows(int T) { return (T + 31) & ~31; }
-// byte offset of (row t, half) inside an utterance, before the (co-tile, q) part: + ct * 4096 + q * 1024; nct = C / 32
-__device__ __forceinline__ int bl_row_off(int t, int half, int nct) { return (t >> 5) * nct * 4096 + half * 512 + (t & 31) * 16; }
-constexpr int BL_OOB = (int)0x80000000;   // an offset every buffer access drops (reads return 0)
-
 // Tuning ablations (skip a phase of a kernel) exist only in builds made with -DDTTS_ABLATE; in the release library the
 // tests below are compile-time false and the branches fold away.
 #ifdef DTTS_ABLATE

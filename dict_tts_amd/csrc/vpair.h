@@ -19,7 +19,6 @@ struct VPairParams {
     int mode;
     int drop_y;           // mode 3 with ya: do not write the fp32 result (nothing reads it after the stage)
     float div, slope;
-    int in_blocked, out_blocked;   // x / y in the blocked layout of rb_common.h ("BL"; DTTS_VOC_F16 only) instead of row-major [B][T][C]
     int el;               // 16-bit operand type of both convolutions: EL_BF16 (rb_common.h) or EL_F16; w1 / w2 are packed in that type
     int pre_off;          // (set by the launcher) byte offset of the tile table in dynamic LDS
     unsigned long long* ovf;     // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null

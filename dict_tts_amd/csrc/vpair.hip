@@ -20,7 +20,7 @@ namespace dtts {
 // TT = 128: 3 workgroups per CU; TT = 256: every weight fragment feeds 8 MFMAs instead of 4 (half the weight stream
 // through the texture path, half the halo), 2 workgroups per CU when the LDS tile allows
 // C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
-template <int C, int TT, int EL, bool GUARD, bool IB, bool OB>
+template <int C, int TT, int EL, bool GUARD>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,39 +91,13 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     // t >= len exceeds num_records) returns zeros = the reference's zero padding, with no per-access compare; a thread
     // keeps its column and walks rows in steps of 8, so each access costs one v_add for its address.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    // (blocked tensors pad every utterance to a multiple of 32 rows; rows >= len are masked by the offset, not by the range)
-    const float* xu = p.x + (IB ? (long long)b * bl_rows(p.T) : brow) * C;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, (IB ? bl_rows(len) : len) * C * 4, 0x00020000);
+    const float* xu = p.x + brow * C;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, len * C * 4, 0x00020000);
     constexpr int RSTEP = 256 / F4;                 // rows between two accesses of a thread (8)
     const int c4 = tid % F4, r0 = tid / F4;
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
-    if (IB && !DTTS_DBG(p, 4)) {
-        // blocked input (rb_common.h "BL"): a 32-row x 32-channel block is 256 pieces of 16 B = one load per thread, 1 KB contiguous per
-        // wave; thread i <-> piece (q = i >> 6, half = (i >> 5) & 1, row i & 31).  Blocks (row tile, co-tile) covering [a0, a0 + arows)
-        constexpr int U = 12;
-        const int pr = tid & 31, pc = (tid >> 6) * 8 + ((tid >> 5) & 1) * 4;   // row in the block, first channel in the co-tile
-        const int poff = (tid >> 6) * 1024 + ((tid >> 5) & 1) * 512 + pr * 16;
-        const int rt0 = a0 >> 5;                                                // (arithmetic shift: floor for a0 < 0)
-        const int nblk = (((a0 + arows - 1) >> 5) - rt0 + 1) * NCT;
-        for (int kb = 0; kb < nblk; kb += U) {
-            u32x4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = kb + u, rt = rt0 + idx / NCT, ct = idx % NCT, t = rt * 32 + pr;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (idx < nblk && t >= 0 && t < len) ? (rt * NCT + ct) * 4096 + poff : BL_OOB, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = kb + u, rt = rt0 + idx / NCT, ct = idx % NCT, lr = rt * 32 + pr - a0;
-                if (idx >= nblk || lr < 0 || lr >= arows) continue;
-                const f32x4 f = __builtin_bit_cast(f32x4, v[u]);
-                if constexpr (GUARD) n_ovf += ovf4(f, 0.1f);
-                *(uint2*)(smem + lr * PITCH + (ct * 32 + pc) * 2) = act4<EL>(f, 0.1f);
-            }
-        }
-    }
-    if (!IB && !DTTS_DBG(p, 4)) {
+    if (!DTTS_DBG(p, 4)) {
 #ifndef VP_U
 #define VP_U 12
 #endif
@@ -192,23 +166,6 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
                 if (!inb) pk = make_uint2(0, 0);
                 *(uint2*)(smem + r * PITCH + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
             }
-        if constexpr (IB || OB) {
-            // tile m's accumulators are free: the residual x of c2's output rows o = m * 32 + (lane & 31) <-> t0 + o comes straight into
-            // them (accumulator layout), c2 then accumulates onto x + b2 — no residual pass, no re-read in the epilogue.  Blocked
-            // input: 1 KB per wave access; row-major input (the stage's first iteration): 32 B per row and access.
-            const int o = m * 32 + (lane & 31), t = t0 + o;
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int off;
-                    if constexpr (IB) off = t < len ? bl_row_off(t, lane >> 5, NCT) + (wc * NT + n) * 4096 + q * 1024 : BL_OOB;
-                    else off = (t * C + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4;
-                    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][n][4 * q + e] = f[e];
-                }
-        }
     }
     __syncthreads();
     VP_STAMP(3);
@@ -219,19 +176,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
-    if constexpr (IB || OB) {
-#pragma unroll
-        for (int m = 0; m < MTT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][n][4 * q + e] += bb[n][q][e];   // x + b2 (tile by tile: the loads are waited for in order)
-        rb_contract<EL, MT, NT, NKG, PITCH, false, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0);
-    } else {
-        rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
-    }
+    rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     VP_STAMP(4);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
@@ -247,47 +192,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     // Buffer loads / stores again: rows >= len are dropped by the range check, the garbage rows o >= TTe of the last
     // slab are sent out of range explicitly.  The reads of slab m+1 are issued before slab m is processed.
     constexpr int PER = 32 * F4 / 256;
-    float* yu = p.y + (OB ? (long long)b * bl_rows(p.T) : brow) * C;
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, (OB ? bl_rows(len) : len) * C * 4, 0x00020000);
-    if constexpr (OB) {
-        // ---- blocked output: every accumulator quad leaves as one 16-byte store per lane (1 KB per wave access), straight from the
-        // registers; the stage sum xs (modes 2 / 3) is read the same way, one tile ahead.  No LDS, no barrier: the stores drain while the
-        // next tile is staged.
-        auto ooff = [&](int m) {
-            const int o = m * 32 + (lane & 31), t = t0 + o;
-            return (o < TTe && t < len) ? bl_row_off(t, lane >> 5, NCT) + wc * NT * 4096 : BL_OOB;
-        };
-        constexpr int SB = NT == 1 ? 2 : 1;   // xs tiles double-buffered only while the registers allow it
-        u32x4 so[SB][NT][4];
-        auto fetch_s = [&](int m, u32x4 (&d)[NT][4]) {
-            const int ro = ooff(m);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) d[n][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ro == BL_OOB ? ro : ro + n * 4096 + q * 1024, 0, 0);
-        };
-        if (p.mode >= 2 && SB == 2) fetch_s(0, so[0]);
-#pragma unroll
-        for (int m = 0; m < MTT; ++m) {
-            if (p.mode >= 2 && SB == 2 && m + 1 < MTT) fetch_s(m + 1, so[(m + 1) & (SB - 1)]);
-            if (p.mode >= 2 && SB == 1) fetch_s(m, so[0]);
-            const int ro = ooff(m);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 o4 = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
-                    if (p.mode >= 2) o4 += __builtin_bit_cast(f32x4, so[m & (SB - 1)][n][q]);   // xs += x
-                    if (p.mode == 3) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] / p.div;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs_y, ro == BL_OOB ? ro : ro + n * 4096 + q * 1024, 0, 0);
-                }
-        }
-        if constexpr (!PS) break;
-        continue;          // (every wave is past the barrier behind c2: the next tile may be staged)
-    }
+    float* yu = p.y + brow * C;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, len * C * 4, 0x00020000);
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ya ? p.ya + brow * C : (unsigned short*)yu), 0, len * C * 2, 0x00020000);
     const int eoff0 = ((t0 + r0) * C + c4 * 4) * 4;
     auto eoff = [&](int m, int u) {                 // byte offset of (slab m, access u) or out of range
@@ -300,8 +206,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            xi[u] = u32x4{0u, 0u, 0u, 0u};
-            if constexpr (!IB) xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);   // (IB: the residual went in as c2's initial accumulators)
+            xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             if (p.mode >= 2) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
         }
     };
@@ -358,7 +263,7 @@ bool vpair_supported(int C, int K, int dil) {
     return (C == 128 || C == 256) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
 }
 
-template <int CC, int TT, int EL, bool GUARD = false, bool IB = false, bool OB = false>
+template <int CC, int TT, int EL, bool GUARD = false>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
@@ -376,17 +281,10 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr bool PS = !(CC == 128 && TT == 128);
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if constexpr (EL == EL_F16 && !IB && !OB) {   // blocked tensors exist in the fp16 mode only
-        if (p.in_blocked && p.out_blocked) return vpair_launch_tt<CC, TT, EL, GUARD, true, true>(p, stream);
-        if (p.in_blocked) return vpair_launch_tt<CC, TT, EL, GUARD, true, false>(p, stream);
-        if (p.out_blocked) return vpair_launch_tt<CC, TT, EL, GUARD, false, true>(p, stream);
-    } else if (!IB && !OB) {
-        if (p.in_blocked || p.out_blocked) return hipErrorInvalidValue;
-    }
     if constexpr (EL == EL_F16 && !GUARD) {
-        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, IB, OB>(p, stream);
+        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true>(p, stream);
     }
-    auto kern = vpair_kernel<CC, TT, EL, GUARD, IB, OB>;
+    auto kern = vpair_kernel<CC, TT, EL, GUARD>;
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;
