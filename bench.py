@@ -364,13 +364,17 @@ def main():
         return lens, wav, T_mel
 
     def timed_loop(n_steps_, n_warm, mode, sync_dist=True):
-        lens_acc = torch.zeros((), dtype=torch.int64, device=dev)
-        for i in range(n_warm * steps_per_pass):  # identical to the timed loop body (torch lazily loads its reduce/add kernels on first use)
+        # valid frames are counted AFTER the loop from the per-step length vectors (kept alive in a list): no bookkeeping kernels of the
+        # harness run between the steps (round 2's `lens_acc += lens.sum()` queued two tiny torch kernels per step behind the
+        # persistent vocoder workgroups: ~0.3 ms each on the text->mel stream)
+        kept_lens = []
+        for i in range(n_warm * steps_per_pass):  # identical to the timed loop body
             lens, _, _ = run_step(i, mode)
             if lens is not None:
-                lens_acc += lens.sum()
-        state["warm_frames"] = int(lens_acc.item())
-        lens_acc.zero_()
+                kept_lens.append(lens)
+        torch.cuda.synchronize()
+        state["warm_frames"] = int(sum(int(l.sum().item()) for l in kept_lens))
+        kept_lens = []
         torch.cuda.synchronize()
         voc.ctx.timer_reset()
         if dist is not None and sync_dist:
@@ -380,12 +384,13 @@ def main():
         for i in range(n_steps_ * steps_per_pass):
             lens, _, _ = run_step(n_warm * steps_per_pass + i, mode)
             if lens is not None:
-                lens_acc += lens.sum()
+                kept_lens.append(lens)
         torch.cuda.synchronize()                 # includes the D2H copies into pinned memory
         if dist is not None and sync_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, int(lens_acc.item())
+        dt = time.perf_counter() - t0
+        return dt, int(sum(int(l.sum().item()) for l in kept_lens))
 
     elapsed, frames_rank = timed_loop(args.steps, args.warmup, args.input)
     main_warm_frames = state["warm_frames"]

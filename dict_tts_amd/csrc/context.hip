@@ -142,6 +142,7 @@ struct dtts_ctx {
     unsigned long long noise_seed = 0;              // per context (dtts_create: time, pid, device, instance; dtts_set_noise_seed overrides)
     unsigned long long* ovf_dev = nullptr;          // fp16 range guard counter (DTTS_VOC_F16), device
     bool guard_on = false;
+    bool voc_span = false;                          // DTTS_TIMER_VOC_CONV: one event pair spans the whole kernel family of a forward (below)
     int amax_cap = 0;
     int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
     bool encoded = false;
@@ -720,6 +721,10 @@ struct Timed {
     Timed(dtts_ctx* h_, int which_, hipStream_t s_) : h(h_), which(which_), s(s_) {
         TimerSlot& t = h->timers[which];
         if (!t.enabled) return;
+        if (which == DTTS_TIMER_VOC_CONV && h->voc_span) {   // inside a family span: count the launch, record nothing
+            t.launches += 1;
+            return;
+        }
         if (t.used + 2 > t.pool.size()) {
             for (int i = 0; i < 256; ++i) {
                 hipEvent_t e;
@@ -931,6 +936,22 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     }
     HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
     const int TV = DTTS_TIMER_VOC_CONV;
+    // The family's launches are consecutive on the stream (nothing else runs between conv_pre and the last ResBlock / conv_post): ONE
+    // hipEvent pair per forward spans them all — the per-launch pairs of round 2 put 50 event packets between the kernels of every forward
+    // (DTTS_TUNE bit 4 brings them back).  The span includes the kernel boundaries; launches are still counted one by one.
+    struct SpanGuard {
+        dtts_ctx* h;
+        Timed* t;
+        ~SpanGuard() {
+            h->voc_span = false;
+            delete t;   // closes the span (records the end event)
+        }
+    } span{h, nullptr};
+    if (h->timers[TV].enabled && !(h->tune & 16)) {
+        span.t = new Timed(h, TV, s);
+        h->timers[TV].launches -= 1;   // (the span itself is not a launch)
+        h->voc_span = true;
+    }
     const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)
     bool post_done = false;
     int Tcur = T, ch = c.upsample_initial_channel;
