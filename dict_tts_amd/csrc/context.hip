@@ -927,7 +927,13 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     bf* Sa = A.alloc<bf>(max_elems);
     bf* melb = A.alloc<bf>((size_t)B * T * melC);
     int* lensS = A.alloc<int>((size_t)(nup + 1) * B);
-    if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    // one tile counter per launch of a persistent kernel (vpair / rblock: dynamic tile claiming), zeroed once per forward
+    constexpr int N_CTR = 64;
+    unsigned* ctrs = A.alloc<unsigned>(N_CTR);
+    int n_ctr = 0;
+    if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !ctrs) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
+    const bool dyn_tiles = !(h->tune & 4);   // DTTS_TUNE bit 2: static tile assignment (round 2)
+    if (dyn_tiles) HIPCHK(hipMemsetAsync(ctrs, 0, N_CTR * sizeof(unsigned), s));
     {
         StageMult mult;
         mult.m[0] = 1;
@@ -1033,6 +1039,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     post_done = true;
                 }
                 rp.el = el;
+                rp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                 rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
@@ -1059,6 +1066,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     vp.div = (float)nk;
                     vp.slope = last_stage ? 0.01f : 0.1f;
                     vp.el = el;
+                    vp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                     vp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
                     vp.dbg = g_ablate >> 8;
 #ifdef DTTS_ABLATE

@@ -25,6 +25,7 @@ struct RBlockParams {
     const float* post_w;   // conv_post weight as [7 taps][C] fp32
     const float* post_b;   // [1]
     int el;                // 16-bit operand type: EL_BF16 (rb_common.h) or EL_F16; the packed weights are in that type
+    unsigned* tile_ctr;    // persistent configurations: device counter (zero at launch) for dynamic tile claiming, or null = static w, w + G, ...
     int pre_off;           // (set by the launcher) byte offset of the tile-count table in dynamic LDS
     unsigned long long* ovf;   // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null
     int dbg;               // -DDTTS_ABLATE builds only; tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act

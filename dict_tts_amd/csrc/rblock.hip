@@ -171,14 +171,26 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;
     // the workgroup's next tile
-    const int jn = j + G;
-    const bool has_next = PS && jn < total;
+    // the workgroup's next tile: static (j + G), or — p.tile_ctr — DYNAMIC: the next unclaimed tile of the launch, taken from a
+    // device counter (tiles 0 .. G-1 are the workgroups' first tiles, the counter hands out G, G+1, ...).  Workgroups slowed down by
+    // whatever shares their CU (the next batch's text->mel kernels on the other stream, a neighbour's phase) then simply take fewer
+    // tiles instead of setting the launch's finish time.  One lane issues the atomic at the top of the tile; its result is not
+    // needed before the epilogue (the x prefetch), where it is broadcast through LDS behind a barrier that exists anyway.
+    unsigned claim = 0;
+    if (PS && p.tile_ctr && tid == 0) claim = atomicAdd(p.tile_ctr, 1u);
+    int jn = j + G;
+    bool has_next = PS && jn < total;
     int bn = b, lenn = len, t0n = 0;
-    if (has_next) {
-        locate(jn, bn);
-        lenn = len_of(bn);
-        t0n = (jn - pre[bn]) * TTo - (p.wav ? PH : 0);
-    }
+    auto plan_next = [&]() {
+        has_next = PS && jn < total;
+        bn = b;
+        if (has_next) {
+            locate(jn, bn);
+            lenn = len_of(bn);
+            t0n = (jn - pre[bn]) * TTo - (p.wav ? PH : 0);
+        }
+    };
+    if (!(PS && p.tile_ctr)) plan_next();
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
     const int goff0 = ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
 
@@ -250,6 +262,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         if (it < 2) load_bias(bb, p.b1[it + 1]);
         rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, p.w1[it + 1] + wlane, kg_stride);
+        if (PS && p.tile_ctr && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
         __syncthreads();               // every wave is done reading xt
         if (it < 2) {
             write_act(xr);
@@ -257,6 +270,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         }
     }
 
+    if (PS && p.tile_ctr) {
+        jn = __builtin_amdgcn_readfirstlane(pre[3 * p.B + 1]);
+        plan_next();
+    }
     if (DTTS_DBG(p, 2)) {
         if (xr[0][0][0] == 123.456f) p.S[0] = 1.f;
         if (has_next) {

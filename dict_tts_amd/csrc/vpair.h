@@ -20,6 +20,7 @@ struct VPairParams {
     int drop_y;           // mode 3 with ya: do not write the fp32 result (nothing reads it after the stage)
     float div, slope;
     int el;               // 16-bit operand type of both convolutions: EL_BF16 (rb_common.h) or EL_F16; w1 / w2 are packed in that type
+    unsigned* tile_ctr;   // persistent configurations: device counter (zero at launch) for dynamic tile claiming, or null = static w, w + G, ...
     int pre_off;          // (set by the launcher) byte offset of the tile table in dynamic LDS
     unsigned long long* ovf;     // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null
     unsigned long long* stats;   // -DDTTS_ABLATE builds only: per-phase cycle sums of wave 0 (see vpair.hip), or null

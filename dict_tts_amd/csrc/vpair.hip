@@ -53,7 +53,12 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
         total = pre[p.B];
     }
 #pragma unroll 1
-    for (int j = PS ? blockIdx.x : 0; j < total; j += gridDim.x) {
+    for (int j = PS ? blockIdx.x : 0; j < total;) {
+    // the next tile: static (j + G) or, with p.tile_ctr, the next unclaimed tile of the launch (rblock.hip: dynamic tile claiming) — the
+    // atomic is issued here, its result is broadcast through LDS behind the barrier that ends the tile
+    unsigned claim = 0;
+    if (PS && p.tile_ctr && tid0 == 0) claim = atomicAdd(p.tile_ctr, 1u);
+    const int j_static = j + (int)gridDim.x;
     // (the thread index passes through an opaque move every tile: everything derived from it is then recomputed per tile — a few
     // VALU instructions — instead of being hoisted out of the tile loop by hipcc and spilled to scratch for lack of registers)
     int tid = tid0;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     if (DTTS_DBG(p, 2)) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
         if constexpr (!PS) break;
+        j = j_static;
         continue;
     }
     // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
@@ -255,7 +261,9 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     }
 #endif
     if constexpr (!PS) break;
+    if (p.tile_ctr && tid0 == 0) pre[3 * p.B + 1] = (int)gridDim.x + (int)claim;
     __syncthreads();   // the epilogue's staging rows alias the tile the next iteration stages into
+    j = p.tile_ctr ? __builtin_amdgcn_readfirstlane(pre[3 * p.B + 1]) : j_static;
     }   // (tiles of this workgroup)
 }
 
