@@ -16,6 +16,7 @@
 #include "rb_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dtts {
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int RPP = THREADS / F4;              // rows one cooperative access of the workgroup covers (32 at C <= 64, 16 at C >= 128)
     constexpr int PER = SROWS / RPP;               // accesses per staging pass of SROWS = 32 rows per time-wave
-    static_assert(THREADS % F4 == 0 && SROWS % RPP == 0 && RPP <= 32, "row-coalesced staging");
+    static_assert(THREADS % F4 == 0 && SROWS % RPP == 0, "row-coalesced staging");
     int c4 = tid % F4, r0 = tid / F4;   // r0 in [0, RPP)
     // staged row s = r0 + RPP * u of pass m <-> tile row: 32-row slab m of time-wave s / 32
     auto tile_row = [&](int m, int u) { const int sr = r0 + RPP * u; return ((sr >> 5) * MT + m) * 32 + (sr & 31); };
@@ -456,6 +457,11 @@ int rblock_padded_taps(int C, int K) {
 // per CU, +1 %: that one keeps one tile per workgroup).
 template <int EL>
 static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream) {
+    // C = 32: k >= 7 on 1024-row tiles (8 waves over time, one persistent workgroup per CU: the 6 (k - 1)-row halo costs 12 % of a
+    // k = 11 tile instead of 23 %; -8 % on that launch), k = 3 on 512-row tiles, two 4-wave workgroups per CU, one tile each (the
+    // 1024-row form is 14 % slower there).  DTTS_RB32=0: 512-row tiles for every k (round 2).
+    static const int rb32 = getenv("DTTS_RB32") ? atoi(getenv("DTTS_RB32")) : 1;
+    if (C == 32 && rb32 && p.K >= 7) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
     if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1, EL, 0>(p, stream);      // 512-row tile, 4 waves over time
     if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
     if (C == 128) return rb_launch_cfg<128, 4, 1, 2, 4, EL, 1>(p, stream);    // 256-row tile, 8 waves (2 time x 4 channel)
