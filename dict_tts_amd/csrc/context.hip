@@ -591,7 +591,12 @@ int build_vocoder(dtts_ctx* h) {
     h->hop = 1;
     for (int i = 0; ok && i < c.n_upsamples; ++i) {
         const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
-        ok = ok && pack_transposed(h, need, h->ups[i], eng, v + "ups." + std::to_string(i), u, (k - u) / 2);
+        // OPTION (DTTS_TUNE bit 13, off by default): ups.1 — the most expensive serial convolution, 8.4 of their 18.9 MFLOP per frame — in the
+        // fp16 two-product form (vconv.hip H2; weights packed as a single fp16 tensor).  Measured: vocoder -0.7 %, pipelined step -0.4 %,
+        // waveform RMS error 4.6e-5 -> 7.2e-5 (gate 1e-4): the gain does not pay for a third of the gate's margin, so three products stay.
+        const bool h2 = c.vocoder_precision == DTTS_VOC_F16 && i == 1 && (h->tune & 8192) && (u * (c.upsample_initial_channel >> (i + 1))) % 256 == 0 &&
+                        (c.upsample_initial_channel >> i) % 128 == 0;
+        ok = ok && pack_transposed(h, need, h->ups[i], h2 ? ENG_F16 : eng, v + "ups." + std::to_string(i), u, (k - u) / 2);
         h->hop *= u;
     }
     const int nk = c.n_resblock_kernels;
@@ -708,6 +713,7 @@ VConvParams vparams_x3(const PackedConv& L, const float* xf, int ld, float in_sl
     p.ldx = ld;
     p.in_slope = in_slope;
     p.wlo = (const uint4*)L.w_lo;
+    p.h2 = L.engine == ENG_F16 ? 1 : 0;
     return p;
 }
 

@@ -12,6 +12,7 @@ struct VConvParams {
     float in_slope;           //   slope of that leaky_relu (1 = identity)
     int C_in;                 //   valid input channels (multiple of 4; channels C_in..C_in_pad are zero)
     const uint4* wlo;         //   bf16 lo pack (w - bf16(w)), same layout as w
+    int h2;                   //   1: fp16 two-product form (vconv.hip H2): w is a SINGLE fp16 pack, wlo unused
     const uint4* w;           // packed bf16 weights (context.hip:pack_conv)
     const float* bias;        // [C_out_pad] (zero padded) or null
     const int* lens;          // [B] valid rows (stride-1 convs: input rows == output rows); null -> T

@@ -14,6 +14,9 @@
 #include "vconv.h"
 #include "rb_common.h"
 
+#ifndef VC_H2_RING
+#define VC_H2_RING 2
+#endif
 namespace dtts {
 
 
@@ -26,14 +29,19 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
 // the bf16 rounding noise, tools/precision_sim.py).  The input is the fp32 tensor itself (leaky_relu(in_slope) applied while
 // staging), split into bf16 hi + lo LDS tiles; weights arrive as hi + lo packs; three MFMAs per step: Wlo*Xhi + Whi*Xlo +
 // Whi*Xhi (16-bit significand products, fp32 accumulation).
-template <int MT, int NT, int WT, int WC, int CK, bool X3>
+// H2 (with X3): two-product form on fp16 operands — activations split into fp16 hi + lo LDS tiles exactly like X3's bf16 pair, weights a
+// SINGLE fp16 pack: W * Xlo + W * Xhi.  The weight rounding (11-bit significand) is the only error left; tools/precision_sim.py scheme
+// "hh/h": 7e-5 waveform RMS when ups.1 alone runs this way (gate 1e-4, 5.3e-5 with three products everywhere).  fp16 hi saturates at
+// 65504 and lo carries the rest, so the pair represents |a| up to 1.3e5.
+template <int MT, int NT, int WT, int WC, int CK, bool X3, bool H2 = false>
 __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
+    static_assert(!H2 || X3, "H2 is a variant of the fp32-input path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
     constexpr int TT = 32 * MT * WT;
     constexpr int CO_T = 32 * NT * WC;
     constexpr int NKG = CK / 16;
-    constexpr int R = X3 ? 2 : (NKG < 4 ? NKG : 4);  // weight-fragment ring slots (X3: three MFMAs per fragment pair, one step of prefetch is enough)
+    constexpr int R = X3 ? (H2 ? VC_H2_RING : 2) : (NKG < 4 ? NKG : 4);  // weight-fragment ring slots (X3: three MFMAs per fragment pair, one step of prefetch is enough)
     constexpr int PF = R - 1;             // prefetch distance in k-steps
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,8 +75,9 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
     // tile is staged (L2 latency overlaps the staging loads); the packed buffer has PF+1 steps of slack at its end.
     const size_t kg_stride = (size_t)NCT * 64;
     const size_t tap_jump = (size_t)NG * NCT * 64 - (size_t)NKG * kg_stride;
-    uint4 ring[R][NT], ringl[X3 ? R : 1][NT];
-    const long long wlo_d = X3 ? (const char*)p.wlo - (const char*)p.w : 0;   // the lo pack mirrors the hi pack: one pointer walks both
+    constexpr bool WLO = X3 && !H2;   // a lo weight pack exists
+    uint4 ring[R][NT], ringl[WLO ? R : 1][NT];
+    const long long wlo_d = WLO ? (const char*)p.wlo - (const char*)p.w : 0;   // the lo pack mirrors the hi pack: one pointer walks both
     auto wlo = [&](const uint4* q) { return *(const uint4*)((const char*)q + wlo_d); };
     const uint4* wpf = p.w + (size_t)ct0 * 64 + lane;
     // polyphase upsamplers (k = 2u): this wave's channels use two of the three taps (the third is all zero)
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 ring[s % R][n] = wpf[n * 64];
-                if constexpr (X3) ringl[s % R][n] = wlo(wpf + n * 64);
+                if constexpr (WLO) ringl[s % R][n] = wlo(wpf + n * 64);
             }
             wpf += kg_stride;
             if ((s + 1) % NKG == 0) wpf += tap_jump;
@@ -114,6 +123,18 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
                     if (idx >= total) continue;
                     float a[4], lo[4];
                     unsigned hb[4];
+                    if constexpr (H2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = lrelu(v[u][e], p.in_slope);
+                            const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);   // saturate: lo carries the rest
+                            hb[e] = (unsigned)__builtin_bit_cast(unsigned short, hh);
+                            lo[e] = a[e] - (float)hh;
+                        }
+                        *(uint2*)(smem + r * PITCH + c * 8) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+                        *(uint2*)(smem + lo_off + r * PITCH + c * 8) = make_uint2(pack2<EL_F16>(lo[0], lo[1]), pack2<EL_F16>(lo[2], lo[3]));
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         a[e] = lrelu(v[u][e], p.in_slope);
@@ -162,7 +183,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {   // step s + PF
                     ring[(kg + PF) % R][n] = wpf[n * 64];
-                    if constexpr (X3) ringl[(kg + PF) % R][n] = wlo(wpf + n * 64);
+                    if constexpr (WLO) ringl[(kg + PF) % R][n] = wlo(wpf + n * 64);
                 }
                 wpf += kg_stride;
                 if ((kg + PF + 1) % NKG == 0) wpf += tap_jump;
@@ -179,6 +200,11 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
+                        if constexpr (H2) {   // fp16, two products: the small one first
+                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xl[kg & 1][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xa[kg & 1][m], acc[m][n]);
+                            continue;
+                        }
                         if constexpr (X3) {   // the two small products first
                             acc[m][n] = mfma16<EL_BF16>(ringl[kg % R][n], xa[kg & 1][m], acc[m][n]);
                             acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xl[kg & 1][m], acc[m][n]);
@@ -357,14 +383,14 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
     }
 }
 
-template <int MT, int NT, int WT, int WC, int CK, bool X3>
+template <int MT, int NT, int WT, int WC, int CK, bool X3, bool H2 = false>
 static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
     constexpr int PITCH = CK * 2 + 16, TT = 32 * MT * WT, CO_T = 32 * NT * WC;
     const int rows = TT + p.K * p.dil;   // incl. one spare tap for the activation-fragment prefetch past the last step
     size_t lds = (size_t)rows * PITCH * (X3 ? 2 : 1);
     const size_t ep = (size_t)WT * 32 * (CO_T * 4 + 16);
     if (ep > lds) lds = ep;
-    auto kern = vconv_kernel<MT, NT, WT, WC, CK, X3>;
+    auto kern = vconv_kernel<MT, NT, WT, WC, CK, X3, H2>;
     static size_t configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
     int cur_dev = 0;
     if (lds > 65536) (void)hipGetDevice(&cur_dev);
@@ -384,7 +410,12 @@ static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
 template <int MT, int NT, int WT, int WC, int CK>
 static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
     if (p.xf) {
-        if (!p.wlo || p.ya) return hipErrorInvalidValue;
+        if (p.ya) return hipErrorInvalidValue;
+        if (p.h2) {   // fp16 two-product form: instantiated for the wide upsampler configuration only
+            if constexpr (MT == 4 && NT == 2 && CK == 128) return vlaunch_x<MT, NT, WT, WC, CK, true, true>(p, stream);
+            return hipErrorInvalidValue;
+        }
+        if (!p.wlo) return hipErrorInvalidValue;
         return vlaunch_x<MT, NT, WT, WC, CK, true>(p, stream);
     }
     return vlaunch_x<MT, NT, WT, WC, CK, false>(p, stream);

@@ -877,6 +877,21 @@ def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
         assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
 
 
+def test_two_product_upsampler_option_stays_inside_the_gate(voc_sd, oracle_voc_sd, monkeypatch):
+    """DTTS_TUNE bit 13 (off by default): ups.1 on fp16 operands with two MFMA products instead of three bf16 ones (vconv.hip H2) —
+    still inside the waveform gate (7e-5), and different from the default mode's result (the option really ran)."""
+    from dict_tts_amd import vocoder
+    from oracle import hifigan_ref as href
+    mel = synth.random_mel(21, 96, "h2")
+    want = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel).numpy()
+    base = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="f16").spec2wav(mel)
+    monkeypatch.setenv("DTTS_TUNE", "8192")
+    opt = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="f16").spec2wav(mel)
+    wave_gate(base, want)
+    wave_gate(opt, want)
+    assert not np.array_equal(base, opt) and rms(base - want) < rms(opt - want)
+
+
 def test_fp16_range_guard_fires_and_falls_back(voc_sd, oracle_voc_sd):
     """fp16 ResBlock operands saturate at 65504 where the reference computes in fp32 (hifigan.py:51-58).  With the
     first stage's ResBlock weights scaled up the activations leave the fp16 range: the guarded kernels COUNT them
