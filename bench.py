@@ -70,7 +70,7 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
     """The CPU oracle (our restatement of the reference, oracle/*.py, pinned by tests/golden) timed on the host cores per
     BASELINE.md §3: reference-faithful protocol = B=1 per utterance, model forward + one spec2wav (tasks/tts/dict_tts.py:179-255),
     3 warm-ups, median of 5 repetitions over ALL 60 rows of the 60-utterance set; plus a batched variant.
-      thread sweep: rows 0..5 x 2 passes at {32, 64, physical cores} torch threads (those that the box has); the best count runs the
+      thread sweep: rows 0..5 x 2 passes at {8, 16, 32, 64, physical cores} torch threads (those that the box has); the best count runs the
                     protocol and is stated as `cores`, all three rates are listed (a B=1 forward does not scale to 128 threads);
       mode 'protocol' (default): all 60 rows, up to 5 repetitions inside a time budget (`budget_s`, at least one full repetition;
                     the number completed is stated), batched variant B=8 (one pass);
@@ -109,7 +109,7 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
     t_start = time.perf_counter()
     # ---- thread sweep (the first pass of each setting is its warm-up)
     sweep = {}
-    cands = sorted({t for t in (32, 64, phys) if 1 <= t <= max(1, logical)}) or [max(1, phys)]
+    cands = sorted({t for t in (8, 16, 32, 64, phys) if 1 <= t <= max(1, logical)}) or [max(1, phys)]
     if mode == "bounded":
         cands = [max(1, phys)]
     kept = None
@@ -162,7 +162,7 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
            "thread_sweep_mel_frames_per_s": sweep,
            "protocol": "BASELINE.md §3: B=1 per utterance (text->mel + one spec2wav), 3 warm-ups, median of the repetitions; "
                        "torch CPU fp32 oracle (oracle/dict_tts_ref.py + oracle/hifigan_ref.py); threads = the best of the sweep "
-                       "{32, 64, physical} measured on rows 0..5",
+                       "{8, 16, 32, 64, physical} measured on rows 0..5",
            "sample": f"rows 0..{n_utt - 1} of the 60-utterance set x {n_reps} repetitions ({int(frames)} frames per repetition), mode={mode}"
                      + (f", time budget {budget_s:.0f} s" if mode == "protocol" else ""),
            "repetitions": n_reps,
