@@ -17,7 +17,7 @@ sd = synth.dict_tts_state_dict(1234)
 sd["dur_predictor.linear.0.bias"] = np.array([3.09], np.float32)
 m = model.PortaSpeech_dict(hparams={})
 m.load_state_dict({k: T(v) for k, v in sd.items()})
-voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config())
+voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config(), precision="f16")
 st = synth.biaobei_struct()
 table = synth.dict_table(1234)
 m.upload_dict_table(table)

@@ -17,7 +17,7 @@ sd = synth.dict_tts_state_dict(1234)
 sd["dur_predictor.linear.0.bias"] = np.array([3.09], np.float32)     # ~22 frames per word, as bench.py
 m = model.PortaSpeech_dict(hparams={})
 m.load_state_dict({k: T(v) for k, v in sd.items()})
-voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config())
+voc = vocoder.HifiGAN(state_dict={k: T(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config(), precision="f16")
 st = synth.biaobei_struct()
 dev = torch.device("cuda")
 
@@ -82,7 +82,8 @@ table = synth.dict_table(1234, full)
 t1 = time.perf_counter()
 m.upload_dict_table(table)
 torch.cuda.synchronize()
-print(f"full dictionary table: {len(table['L'])} entries, {table['keys'].shape[0]} gloss rows, {table['keys'].nbytes / 2**20:.0f} MiB; "
+print(f"full dictionary table: {len(table['L'])} entries, {table['keys'].shape[0]} gloss rows, {table['keys'].nbytes / 2**20:.0f} MiB of raw gloss rows on the host, "
+      f"{table['keys'].shape[0] * 2 * 192 * 4 / 2**20:.0f} MiB resident (projected K + V, 192 wide each); "
       f"host build {t1 - t0:.1f} s, upload {time.perf_counter() - t1:.2f} s (once)")
 ib = synth.make_id_batch(sents, table, pron_every=3)
 ids = (T(ib["word_tokens"]).to(dev), T(ib["entry_ids"]).to(dev).to(torch.int32), T(ib["pron_modified"]).to(dev), ib["L_k"], ib["P"])
