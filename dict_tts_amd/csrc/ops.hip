@@ -318,6 +318,9 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
 // ---------------------------------------------------------------------------------------------------------
 // S2PA dictionary attention: one block per word, gloss rows streamed once with 16 B/lane loads.
 constexpr int S2PA_LMAX = 1024, S2PA_DMAX4 = 3;  // D <= 768 (3 float4 per lane), L_k <= 1024
+#ifndef S2PA_RU_P
+#define S2PA_RU_P 8
+#endif
 constexpr int S2PA_NW = 4, S2PA_RU = 4;           // waves per workgroup; gloss rows a wave keeps in flight (3 x 16 B per lane each)
 constexpr int S2PA_NTHR = S2PA_NW * 64;
 
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
 
 hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
     if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
-    if (a.D <= 256) hipLaunchKernelGGL((s2pa_kernel<1, 8>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
+    if (a.D <= 256) hipLaunchKernelGGL((s2pa_kernel<1, S2PA_RU_P>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
     else hipLaunchKernelGGL((s2pa_kernel<S2PA_DMAX4, S2PA_RU>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
     return hipGetLastError();
 }
