@@ -54,6 +54,10 @@ def load_library(path=None):
     if _lib is not None:
         return _lib
     path = path or LIB_PATH
+    try:   # PyTorch-ROCm bundles its own HIP runtime: load it FIRST so that this library binds to the same one (a process that loads
+        import torch  # noqa: F401  # the system libamdhip64 first and torch's afterwards ends up with two runtimes and no visible device)
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise DttsError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C dict_tts_amd/csrc` (there is no CPU fallback for the HIP path)")
