@@ -240,7 +240,11 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
     L.flops_per_row = flops_per_row >= 0 ? flops_per_row : 2.0 * C_out * C_in * K;
     const int KG = engine == ENG_F32 ? 8 : 16, E = KG / 2;
     const int NG = L.C_in_pad / KG, NCT = L.C_out_pad / 32;
-    const size_t n = (size_t)K * L.C_in_pad * L.C_out_pad + (size_t)8 * 16 * L.C_out_pad;  // + 8 zero k-steps of slack (prefetch past the end)
+    // + zero k-steps of slack behind the last tap: the kernels prefetch weight fragments past the end instead of clamping.  vconv walks
+    // one C_in CHUNK at a time and, at the end of a chunk's last tap, its running pointer wraps to "next tap, same chunk" = up to a whole
+    // tap's k-groups (NG) beyond the end for the last chunk (found in round 3: the 192 -> 2048 conditioning convolution read one
+    // 64 KB step past the old 8-step slack — a GPU page fault whenever the allocation ended on a mapped-region boundary)
+    const size_t n = (size_t)K * L.C_in_pad * L.C_out_pad + (size_t)(L.C_in_pad / 16 + 8) * 16 * L.C_out_pad;
     std::vector<float> wf;
     std::vector<uint16_t> whi, wlo;
     if (engine == ENG_F32) wf.assign(n, 0.f);
