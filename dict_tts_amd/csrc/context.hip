@@ -122,7 +122,7 @@ struct dtts_ctx {
     std::vector<PackedConv> dur_conv;
     std::vector<float*> dur_g, dur_b;
     float *dur_w = nullptr, *dur_bias = nullptr;
-    PackedConv g_pre, dec_pre, dec_out;
+    PackedConv g_pre, g_pre_poly, dec_pre, dec_out;   // g_pre_poly: the strided g_pre_net as a 3-tap convolution over 4-frame groups (vconv), or empty
     std::vector<Flow> flows;  // in execution (reversed) order
     float* fs_w = nullptr;    // packed weights of the fused prior-flow kernel (flowstack.hip), or null = launch by launch
     PackedConv fs_cond;       // cond_layer of ALL blocks as one 1x1 convolution (execution order)
@@ -481,6 +481,25 @@ int build_acoustic(dtts_ctx* h) {
     ok = ok && h->dur_w && h->dur_bias;
     // FVAE
     ok = ok && pack_plain(h, need, h->g_pre, (c.decoder_fp32 || (h->tune & 1024)) ? ENG_F32 : ENG_BF16X3, m + "fvae.g_pre_net.0", 1, 4, 2);   // DTTS_TUNE bit 10: fp32 (round 2)
+    // g_pre_net = Conv1d(k = 8, stride 4, pad 2) as a STRIDE-1, 3-tap convolution over 4-frame groups: [B][T][C] is also [B][T/4][4C]
+    // (T is a multiple of frames_multiple = 4), out[q] = sum_j W_j x[4q + j - 2] reads group q - 1 (frames 2, 3), q (all four) and q + 1
+    // (frames 0, 1) — on the split-operand vconv kernel, which skips the two all-zero half taps per input chunk (vconv.hip: in_half).
+    // DTTS_TUNE bit 16: the strided form on the generic kernel.
+    h->g_pre_poly = PackedConv();
+    if (ok && !c.decoder_fp32 && !(h->tune & 1024) && !(h->tune & 65536) && c.frames_multiple == 4 && c.hidden_size % 64 == 0) {
+        const HostTensor* wg = folded_weight(h, need, m + "fvae.g_pre_net.0");
+        std::vector<float> bg = bias_of(need, m + "fvae.g_pre_net.0");
+        if (wg && wg->shape.size() == 3 && wg->shape[2] == 8 && !bg.empty()) {
+            const int Co = (int)wg->shape[0], Ci = (int)wg->shape[1];
+            const float* pw = wg->f.data();
+            ok = pack_conv(h, h->g_pre_poly, ENG_BF16X3, Co, 4 * Ci, 3,
+                           [=](int co, int cip, int tap) {
+                               const int ph = cip / Ci, ci = cip % Ci, j = 4 * (tap - 1) + ph + 2;
+                               return (j >= 0 && j < 8) ? pw[((size_t)co * Ci + ci) * 8 + j] : 0.f;
+                           },
+                           bg, 1, 1, 1, 0, 2.0 * Co * Ci * 8);
+        }
+    }
     const int half = c.latent_size / 2;
     h->flows.clear();
     int parity = 0;
@@ -1852,7 +1871,15 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
     LAUNCH(expand_launch(h->weo, h->m2w, g, h->x_mask, B, h->T_w, T, C, s));
     // A8: g_sqz = Conv1d(k=8, s=4, p=2)(g)
     ConvParams p = base_params(g, C, B, T, T4, gs, C);
-    LAUNCH(conv1d_launch(h->g_pre, p, s));
+    if (h->g_pre_poly.w_hi) {
+        VConvParams v = vparams_x3(h->g_pre_poly, g, 4 * C, 1.f, nullptr, B, T4);
+        v.in_half = 1;
+        v.yf = gs;
+        v.ldyf = C;
+        LAUNCH(vconv_launch(v, s));
+    } else {
+        LAUNCH(conv1d_launch(h->g_pre, p, s));
+    }
     if (z_p) {
         if (z_ld && z_ld < T4) return fail(h, DTTS_E_INVAL, "prior sample holds %d steps per row, T_mel/4 = %d", z_ld, T4);
         LAUNCH(transpose_cf_to_cl_launch(z_p, z, B, Z, T4, s, z_ld));

@@ -41,6 +41,7 @@ struct VConvParams {
     const float* res_b;       // residual of the second segment
     int ldres_b;
     int small_tiles;          // X3: 64-row tiles (4 workgroups / CU) for the memory-bound narrow upsamplers (C_out_pad 128 / 64)
+    int in_half;              // the first half of the INPUT channels skips the first tap, the second half the last (the polyphase g_pre_net)
     int poly_half;            // PackedConv::poly_half: waves in the first half of the packed channels skip the last tap, the others the first
     float div;                // 1 or num_kernels (true division)
     int post_tanh;

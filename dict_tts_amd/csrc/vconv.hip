@@ -87,7 +87,16 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
         tap_lo = second ? 1 : 0;
         tap_hi = second ? p.K : p.K - 1;
     }
+    // in_half (the strided g_pre_net as a 3-tap convolution over 4-row phase groups, context.hip: pack_gpre_poly): the first half of the
+    // INPUT channels has an all-zero first tap, the second half an all-zero last tap — the tap range follows the chunk
+    auto chunk_taps = [&](int ci0) {
+        if (!p.in_half) return;
+        const bool second = ci0 >= (p.C_in_pad >> 1);
+        tap_lo = second ? 0 : 1;
+        tap_hi = second ? p.K - 1 : p.K;
+    };
     auto preload = [&](int ci0) {
+        chunk_taps(ci0);
         wpf = p.w + (((size_t)tap_lo * NG + (ci0 >> 4)) * NCT + ct0) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
