@@ -14,6 +14,9 @@
 #include "vconv.h"
 #include "rb_common.h"
 
+#ifndef VC_SB
+#define VC_SB 1
+#endif
 #ifndef VC_H2_RING
 #define VC_H2_RING 2
 #endif
@@ -176,8 +179,13 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
             }
         }
         __syncthreads();
-        // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s
-        uint4 xa[2][MT], xl[X3 ? 2 : 1][MT];
+        // activation fragments are double-buffered in registers: step s+1 is read from LDS before the MFMAs of step s.
+        // SB (the two-co-tile split-operand configuration: 128 accumulators + hi / lo rings + two fragment sets = 256 VGPRs and 9-12
+        // spilled): ONE fragment set; row tile m's next fragments are read right behind the MFMAs that consumed the current ones and land
+        // while the other row tiles' MFMAs execute.
+        constexpr bool SB = VC_SB && X3 && NT == 2;
+        constexpr int XB = SB ? 1 : 2;
+        uint4 xa[XB][MT], xl[X3 ? XB : 1][MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             xa[0][m] = *(const uint4*)(smem + xoff + tap_lo * p.dil * PITCH + m * 32 * PITCH);
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
                 }
                 wpf += kg_stride;
                 if ((kg + PF + 1) % NKG == 0) wpf += tap_jump;
-                {
-                    const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow + dilP;   // LDS tile has one spare tap of rows
+                const int nxt = (kg + 1 < NKG) ? arow + (kg + 1) * 32 : arow + dilP;   // LDS tile has one spare tap of rows
+                if constexpr (!SB) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         xa[(kg + 1) & 1][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
@@ -206,20 +214,27 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
                 }
                 __builtin_amdgcn_sched_barrier(0);  // the prefetches above stay above this step's MFMAs
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         if constexpr (H2) {   // fp16, two products: the small one first
-                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xl[kg & 1][m], acc[m][n]);
-                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xa[kg & 1][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xl[kg & (XB - 1)][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_F16>(ring[kg % R][n], xa[kg & (XB - 1)][m], acc[m][n]);
                             continue;
                         }
                         if constexpr (X3) {   // the two small products first
-                            acc[m][n] = mfma16<EL_BF16>(ringl[kg % R][n], xa[kg & 1][m], acc[m][n]);
-                            acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xl[kg & 1][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_BF16>(ringl[kg % R][n], xa[kg & (XB - 1)][m], acc[m][n]);
+                            acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xl[kg & (XB - 1)][m], acc[m][n]);
                         }
-                        acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xa[kg & 1][m], acc[m][n]);
+                        acc[m][n] = mfma16<EL_BF16>(ring[kg % R][n], xa[kg & (XB - 1)][m], acc[m][n]);
                     }
+                    if constexpr (SB) {   // this row tile's fragments of the next step, behind the MFMAs that read the current ones
+                        __builtin_amdgcn_sched_barrier(0);
+                        xa[0][m] = *(const uint4*)(smem + nxt + m * 32 * PITCH);
+                        xl[0][m] = *(const uint4*)(smem + lo_off + nxt + m * 32 * PITCH);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             arow += dilP;
