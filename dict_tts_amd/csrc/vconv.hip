@@ -17,6 +17,9 @@
 #ifndef VC_SB
 #define VC_SB 1
 #endif
+#ifndef VC_SB1
+#define VC_SB1 1   // the one-co-tile split-operand configurations (decoder WaveNet): one fragment set, three workgroups per CU
+#endif
 #ifndef VC_H2_RING
 #define VC_H2_RING 2
 #endif
@@ -37,7 +40,7 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
 // "hh/h": 7e-5 waveform RMS when ups.1 alone runs this way (gate 1e-4, 5.3e-5 with three products everywhere).  fp16 hi saturates at
 // 65504 and lo carries the rest, so the pair represents |a| up to 1.3e5.
 template <int MT, int NT, int WT, int WC, int CK, bool X3, bool H2 = false>
-__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
+__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 : 2)) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
     static_assert(!H2 || X3, "H2 is a variant of the fp32-input path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : 2) : (NT == 1 ? 3 : 2)) vo
         // SB (the two-co-tile split-operand configuration: 128 accumulators + hi / lo rings + two fragment sets = 256 VGPRs and 9-12
         // spilled): ONE fragment set; row tile m's next fragments are read right behind the MFMAs that consumed the current ones and land
         // while the other row tiles' MFMAs execute.
-        constexpr bool SB = VC_SB && X3 && NT == 2;
+        constexpr bool SB = X3 && ((VC_SB && NT == 2) || (VC_SB1 && NT == 1 && MT == 4));
         constexpr int XB = SB ? 1 : 2;
         uint4 xa[XB][MT], xl[X3 ? XB : 1][MT];
 #pragma unroll
