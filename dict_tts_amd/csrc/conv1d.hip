@@ -10,6 +10,8 @@
 // For fp32 each lane reads 4 consecutive channels (one ds_read_b128) and spends them on 4 successive
 // 32x32x2 MFMAs; the weight packing uses the same k permutation, so the contraction is unchanged.
 #include "conv1d.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace dtts {
 
@@ -23,10 +25,7 @@ __device__ __forceinline__ unsigned f2bf(float f) {  // round-to-nearest-even fp
 }
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 
-// FULL: the whole input width C_in_pad is staged ONCE (LDS rows of C_in_pad elements) and the CK-chunks are contracted from it back to
-// back in the same order — bit-identical to the chunk-by-chunk form, without its per-chunk staging round trip and two barriers.  For the
-// short-sequence configurations (one workgroup per CU, one wave per SIMD: nothing else hides those latencies).
-template <int ENGINE, int MT, int NT, int WT, int WC, int CK, bool FULL = false>
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
 __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
@@ -48,7 +47,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
     const int in0 = t0 * p.stride - p.pad;
     const int NG = p.C_in_pad / KG;
-    const int pitch = FULL ? p.C_in_pad * ES + 16 : PITCH;   // (C_in_pad * ES + 16) mod 256 == 16 as well for the widths in use: same bank spread
+    constexpr int pitch = PITCH;
     char* lds_lo = smem + (size_t)rows * pitch;
 
     f32x16 acc[MT][NT];
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     // batches of U independent 16 B loads in flight per thread, then conversion + LDS writes
     auto stage = [&](int ci0, int width, int col0) {
         constexpr int U = 4;
-        const int PIECES = FULL ? width / 4 : CK / 4;
+        constexpr int PIECES = CK / 4;
         const int total = rows * PIECES;
         for (int base = tid; base < total; base += 256 * U) {
             f32x4 vv[U];
@@ -103,15 +102,9 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
         }
     };
     if (live) {
-        if constexpr (FULL) {
-            stage(0, p.C_in_pad, 0);
-            __syncthreads();
-        }
         for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
-            if constexpr (!FULL) {
-                stage(ci0, CK, 0);
-                __syncthreads();
-            }
+            stage(ci0, CK, 0);
+            __syncthreads();
             // ---- contraction over taps and k-groups of this chunk.  Steps s = tap * NKG + kg; weight fragments
             // run PF steps ahead in a register ring, activation fragments one step ahead (double buffer); the
             // sched_barriers keep those prefetches above the MFMAs of the current step.
@@ -136,7 +129,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                         if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[off + ctc[n] * 64];
                     }
                 };
-                const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + (FULL ? ci0 * ES : 0);
+                const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES;
                 auto load_x = [&](uint4 (&dh)[MT], uint4 (&dl)[MT], int s) {
                     const int sc = s < S ? s : S - 1;
                     const int off = abase + (sc / NKG) * p.dil * pitch + (sc % NKG) * KG * ES;
@@ -185,7 +178,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
                     }
                 }
             }
-            if constexpr (!FULL) __syncthreads();
+            __syncthreads();
         }
     }
 
@@ -245,39 +238,448 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     }
 }
 
-template <int ENGINE, int MT, int NT, int WT, int WC, int CK, bool FULL = false>
+#ifndef C1D_PROF
+#define C1D_PROF 0
+#endif
+#if C1D_PROF
+__device__ unsigned long long c1d_prof[4][2048][8];
+extern "C" int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(c1d_prof), sizeof(c1d_prof)); }
+#define STAMP(i) if (pslot >= 0 && threadIdx.x == 0) { c1d_prof[pslot][pwg][i] = __builtin_readcyclecounter(); }
+#else
+#define STAMP(i)
+#endif
+template <int ENGINE, int NT, int WC, int KS, int U>
+__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_kernel(const ConvParams p) {
+    constexpr int MT = 1, WT = 1;   // one 32-row time tile per workgroup
+    static_assert(WC * KS == 4, "four waves: co-tile groups x contraction splits");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if C1D_PROF
+    const int pslot = (p.K == 5 && p.C_out == 768) ? 0 : (p.K == 1 && p.C_out == 576) ? 1 : (p.K == 1 && p.C_in == 768 && p.T_out <= 64) ? 2 : (p.K == 1 && p.C_out == 192 && p.C_in == 192) ? 3 : -1;
+    const int pwg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (pslot >= 0 && threadIdx.x == 0) { c1d_prof[pslot][pwg][6] = __builtin_amdgcn_s_memrealtime(); c1d_prof[pslot][pwg][5] = 0; c1d_prof[pslot][pwg][3] = 0; }
+    STAMP(0)
+#endif
+    constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
+    constexpr int KG = (ENGINE == ENG_F32) ? 8 : 16;  // channels per k-group (one 16-B fragment per lane)
+    constexpr int TT = 32 * MT * WT;
+    constexpr int CO_T = 32 * NT * WC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % WT, wc = (wave / WT) % WC;
+    const int ks = __builtin_amdgcn_readfirstlane(wave / (WT * WC));   // which part of the contraction this wave sums (KS > 1)
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * TT;
+    const int ct0 = blockIdx.y * (CO_T / 32) + wc * NT;  // first packed co-tile of this wave
+    const int NCT = p.C_out_pad >> 5;
+    const int in_len = p.in_lens ? p.in_lens[b] : p.T_in;
+    const int out_len = p.out_lens ? p.out_lens[b] : p.T_out;
+    const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
+    const int in0 = t0 * p.stride - p.pad;
+    const int NG = p.C_in_pad / KG;
+    const int pitch = p.C_in_pad * ES + 16;   // +16 B: conflict-free ds_read_b128 across 16 rows ((C_in_pad * ES + 16) mod 256 == 16 for the widths in use)
+    char* lds_lo = smem + (size_t)rows * pitch;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const float* xb = p.x + (long long)b * p.x_bstride + p.x_coff;
+    const bool live = t0 < out_len;
+#if C1D_PROF
+    if (pslot >= 0 && threadIdx.x == 0) c1d_prof[pslot][pwg][5] = 1 + live;
+#endif
+
+    // ---- stage X[in0 .. in0+rows) x [0, C_in_pad) into LDS (pre-activation, zero padding, conversion): U independent 16 B loads in
+    // flight per thread (the launcher picks U so that the whole tile is ONE batch where the registers allow), then conversion + LDS writes.  The rows are requested before the utterance's length is known (up to the padded
+    // T_in, masked afterwards): kernel arguments -> lengths -> rows would be one more round trip with nothing to hide it.
+    {
+        const int PIECES = p.C_in_pad / 4;
+        const int total = rows * PIECES;
+        // piece idx = r * PIECES + c4 walked incrementally (256 pieces per hop): one division per thread, not two per piece
+        // (one wave per SIMD in the short-sequence configurations: every instruction of this loop is on the critical path)
+        const int dr = 256 / PIECES, dc = 256 % PIECES;
+        int r = tid / PIECES, c4 = tid - r * PIECES;
+        for (int base = tid; base < total; base += 256 * U) {
+            f32x4 vv[U];
+            int ru[U], cu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ru[u] = r;
+                cu[u] = c4;
+                const int t = in0 + r, ci = c4 * 4;
+                vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < rows && t >= 0 && t < p.T_in && ci < p.C_in) vv[u] = *(const f32x4*)(xb + (long long)t * p.ldx + ci);
+                r += dr;
+                c4 += dc;
+                if (c4 >= PIECES) {
+                    c4 -= PIECES;
+                    ++r;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ru[u] >= rows) continue;
+                const int r = ru[u], c4 = cu[u];
+                f32x4 v = vv[u];
+                if (in0 + r >= in_len) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.pre_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+                }
+                if constexpr (ENGINE == ENG_F32) {
+                    *(f32x4*)(smem + r * pitch + c4 * 16) = v;
+                } else {
+                    unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+                    *(uint2*)(smem + r * pitch + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    if constexpr (ENGINE == ENG_BF16X3) {
+                        unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
+                        unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
+                        *(uint2*)(lds_lo + r * pitch + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                    }
+                }
+            }
+        }
+    }
+    // ---- the epilogue's operands (bias, residual rows) of output tile (m, n): requested ABOVE the contraction, all 16 rows in flight
+    // at once (one wave per SIMD: nothing else would hide the round trip in the epilogue)
+    struct EpiOperands {
+        bool valid;
+        int co;
+        float bias, bias_s;
+        float r1[16], r2[16];
+    };
+    auto epi_fetch = [&](int m, int n, EpiOperands& eo) {
+        eo.valid = false;
+        if (KS > 1 && ks > 0) return;
+        if (p.gate_H && (n & 1)) return;
+        const int ct = ct0 + n;
+        if (ct >= NCT) return;
+        const int co = (p.gate_H ? (ct >> 1) : ct) * 32 + (lane & 31);   // gated: tanh channel; its sigmoid channel = gate_H + co
+        if (co >= (p.gate_H ? p.gate_H : p.C_out)) return;
+        eo.valid = true;
+        eo.co = co;
+        eo.bias = p.bias ? p.bias[co] : 0.f;
+        eo.bias_s = (p.gate_H && p.bias) ? p.bias[p.gate_H + co] : 0.f;
+        const int s = (co >= p.split) ? 1 : 0;
+        const ConvSeg& sg = p.seg[s];
+        const int cs = co - (s ? p.split : 0);
+        const int tb = t0 + (wt * MT + m) * 32 + 4 * (lane >> 5);
+        const long long row0 = (long long)b * p.y_bstride_rows;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) eo.r1[r] = eo.r2[r] = 0.f;
+        if (sg.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tb + (r & 3) + 8 * (r >> 2);
+                if (t < p.T_out && t < out_len) eo.r1[r] = sg.res[(row0 + t) * sg.ld_res + sg.coff_res + cs];
+            }
+        }
+        if (sg.res2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tb + (r & 3) + 8 * (r >> 2);
+                if (t < p.T_out && t < out_len) eo.r2[r] = sg.res2[(row0 + t) * sg.ld_res2 + sg.coff_res2 + cs];
+            }
+        }
+    };
+    EpiOperands early[MT][NT];
+    __syncthreads();
+    // a tile beyond its utterance leaves after the staging
+    if (t0 >= out_len && !p.zero_masked) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) epi_fetch(m, n, early[m][n]);
+    STAMP(1)
+    // one step's MFMAs: weight fragments bh/bl x activation fragments ah/al into every (m, n) accumulator
+    auto mma = [&](const uint4 (&bh)[NT], const uint4 (&bl)[NT], const uint4 (&ah)[MT], const uint4 (&al)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                // (a co-tile past the layer's last one computes on a clamped copy; the epilogue drops it)
+                if constexpr (ENGINE == ENG_F32) {
+                    const f32x4 a = *(const f32x4*)&ah[m];
+                    const f32x4 w = *(const f32x4*)&bh[n];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], w[q], acc[m][n], 0, 0, 0);
+                } else {
+                    const bf16x8 a = *(const bf16x8*)&ah[m];
+                    const bf16x8 w = *(const bf16x8*)&bh[n];
+                    if constexpr (ENGINE == ENG_BF16X3) {
+                        const bf16x8 a2 = *(const bf16x8*)&al[m];
+                        const bf16x8 w2 = *(const bf16x8*)&bl[n];
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[m][n], 0, 0, 0);
+                }
+            }
+    };
+    // ---- short-sequence contraction: the tile is staged whole, so the steps (tap, k-group) run as ONE sequence per wave (the
+    // weight ring is never restarted), and the KS waves of an output tile each sum 1/KS of the k-groups of every tap — the
+    // fp32 MFMA chain of one wave (64 cycles per 32x32x2) is what bounds these kernels, not the matrix rate.  Partial sums
+    // meet in LDS in a fixed order (ks = 0 + 1 + 2 + 3).
+    if (live) {
+        constexpr int R = 4, PF = 3;
+        const int NGW = NG / KS;                      // k-groups per tap and wave (the launcher checks NG % KS == 0)
+        const int S = p.K * NGW;
+        const int kg_stride_i = NCT * 64, tap_wrap_w = (NG - NGW) * NCT * 64;
+        const uint4* wh = (const uint4*)p.w_hi + (size_t)ks * NGW * NCT * 64 + lane;
+        const uint4* wl = (const uint4*)p.w_lo + (size_t)ks * NGW * NCT * 64 + lane;
+        int ctc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ctc[n] = ct0 + n < NCT ? ct0 + n : NCT - 1;
+        // two cursors over the wave's step sequence (weights run PF steps ahead, activations one), advanced by adds; both stop on
+        // the last step
+        int wo = 0, wg = 0, ws = 0;
+        auto load_w = [&](uint4 (&dh)[NT], uint4 (&dl)[NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                dh[n] = wh[wo + ctc[n] * 64];
+                if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[wo + ctc[n] * 64];
+            }
+            if (ws + 1 < S) {
+                ++ws;
+                wo += kg_stride_i;
+                if (++wg == NGW) {
+                    wg = 0;
+                    wo += tap_wrap_w;
+                }
+            }
+        };
+        const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + ks * NGW * KG * ES;
+        const int tap_wrap_x = p.dil * pitch - NGW * KG * ES;
+        int xo = 0, xg = 0, xs = 0;
+        auto load_x = [&](uint4 (&dh)[MT], uint4 (&dl)[MT]) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                dh[m] = *(const uint4*)(smem + abase + xo + m * 32 * p.stride * pitch);
+                if constexpr (ENGINE == ENG_BF16X3) dl[m] = *(const uint4*)(lds_lo + abase + xo + m * 32 * p.stride * pitch);
+            }
+            if (xs + 1 < S) {
+                ++xs;
+                xo += KG * ES;
+                if (++xg == NGW) {
+                    xg = 0;
+                    xo += tap_wrap_x;
+                }
+            }
+        };
+        uint4 rh[R][NT], rl[R][NT], xh[2][MT], xl[2][MT];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) load_w(rh[j], rl[j]);
+        load_x(xh[0], xl[0]);
+        for (int s = 0; s < S; s += R) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                load_w(rh[(j + PF) % R], rl[(j + PF) % R]);
+                load_x(xh[(j + 1) & 1], xl[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + j < S) mma(rh[j], rl[j], xh[j & 1], xl[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (KS > 1) {
+            __syncthreads();   // every wave is done with the staged rows: their LDS takes the partial sums
+            float* red = (float*)smem;
+            const int tile = wave % (WT * WC);
+            if (ks > 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            red[(((((ks - 1) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane] = acc[m][n][r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[m][n][r] += red[(((((k2 - 1) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (KS > 1 && ks > 0) return;
+
+    // ---- epilogue
+    STAMP(2)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const EpiOperands& eo = early[m][n];
+            if (!eo.valid) continue;
+            const int co = eo.co, co_s = p.gate_H + co;
+            const int s = (co >= p.split) ? 1 : 0;
+            const ConvSeg& sg = p.seg[s];
+            const int cs = co - (s ? p.split : 0);
+            const float bias = eo.bias, bias_s = eo.bias_s;
+            // each optional step applied to all 16 rows under ONE uniform branch (straight-line bodies; masked rows compute on
+            // whatever the accumulator holds and are replaced by zero or dropped at the store)
+            const int tb = t0 + (wt * MT + m) * 32 + 4 * (lane >> 5);
+            const long long row0 = (long long)b * p.y_bstride_rows + tb;
+            const int t_end = out_len < p.T_out ? out_len : p.T_out;     // rows below it are computed, rows in [t_end, T_out) zeroed or kept
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] + bias;
+            if (p.gate_H) {
+                float u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = acc[m][n + (NT > 1 ? 1 : 0)][r] + bias_s;
+                if (p.cond) {
+                    const float* c = p.cond + row0 * p.ld_cond + p.cond_coff;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dt = (r & 3) + 8 * (r >> 2);
+                        if (tb + dt < t_end) {
+                            v[r] += c[(long long)dt * p.ld_cond + co];
+                            u[r] += c[(long long)dt * p.ld_cond + co_s];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]) * (1.f / (1.f + expf(-u[r])));
+            }
+            if (sg.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += eo.r1[r];
+            }
+            if (sg.res2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += eo.r2[r];
+            }
+            if (p.out_div != 1.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] / p.out_div;
+            }
+            if (p.out_mul != 1.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] * p.out_mul;
+            }
+            if (p.post_act == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.post_act == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+            } else if (p.post_act == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));  // F.gelu (erf form)
+            }
+            float* yp = sg.y + row0 * sg.ld + sg.coff + cs;
+            const int t_store = p.zero_masked ? p.T_out : t_end;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dt = (r & 3) + 8 * (r >> 2);
+                if (tb + dt < t_store) yp[(long long)dt * sg.ld] = tb + dt < t_end ? v[r] : 0.f;
+            }
+        }
+    }
+    STAMP(3)
+#if C1D_PROF
+    if (pslot >= 0 && threadIdx.x == 0) c1d_prof[pslot][pwg][7] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+template <int ENGINE, int MT, int NT, int WT, int WC, int CK>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
     constexpr int PITCH = CK * ES + 16;
     constexpr int TT = 32 * MT * WT, CO_T = 32 * NT * WC;
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
-    size_t lds = (size_t)rows * (FULL ? p.C_in_pad * ES + 16 : PITCH) * (ENGINE == ENG_BF16X3 ? 2 : 1);
-    auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK, FULL>;
-    static size_t configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
-    int cur_dev = 0;
-    if (lds > 65536) (void)hipGetDevice(&cur_dev);
-    size_t& configured = configured_dev[cur_dev & 63];
-    if (lds > 65536 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    const size_t lds = (size_t)rows * PITCH * (ENGINE == ENG_BF16X3 ? 2 : 1);
+    auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK>;
     dim3 grid((p.T_out + TT - 1) / TT, (p.C_out_pad + CO_T - 1) / CO_T, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
+// LDS of one short-sequence tile: 32 output rows' receptive field x the whole input width (+ the partial sums of a split contraction)
+static size_t short_lds(const ConvParams& p, int es, int planes, int red_tiles) {
+    const size_t rows = (size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1;
+    const size_t tile = rows * ((size_t)p.C_in_pad * es + 16) * planes, red = (size_t)red_tiles * 16 * 64 * sizeof(float);
+    return tile > red ? tile : red;
+}
+
+static int cu_count() {
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return n_cu;
+}
+
+template <int ENGINE, int NT, int WC, int KS, int U>
+static hipError_t launch_short_u(const ConvParams& p, hipStream_t stream) {
+    constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
+    constexpr size_t LDS_CU = 160 * 1024;
+    const size_t lds = short_lds(p, ES, ENGINE == ENG_BF16X3 ? 2 : 1, (KS - 1) * WC * NT);
+    auto kern = conv1d_short_kernel<ENGINE, NT, WC, KS, U>;
+    static bool configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (!configured_dev[cur_dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CU);
+        if (e != hipSuccess) return e;
+        configured_dev[cur_dev & 63] = true;
+    }
+    dim3 grid((p.T_out + 31) / 32, (p.C_out_pad + 32 * NT * WC - 1) / (32 * NT * WC), p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int ENGINE, int NT, int WC, int KS>
+static hipError_t launch_short(const ConvParams& p, hipStream_t stream) {
+    // 16 B pieces of the staged tile per thread: 8 in flight at 4 workgroups per CU (<= 128 VGPRs), or 24 for the wide tiles (LDS
+    // leaves one workgroup per CU anyway)
+    const size_t pieces = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4);
+    return pieces <= 256 * 8 ? launch_short_u<ENGINE, NT, WC, KS, 8>(p, stream) : launch_short_u<ENGINE, NT, WC, KS, 24>(p, stream);
+}
+
 template <int ENGINE, int CK>
 static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStream_t stream) {
     if constexpr (ENGINE == ENG_F32) {
-        // short sequences (the T_w ~ 27 encoder, B = 1): latency-bound by the serial fp32 MFMA chain of one wave (64 cycles per
-        // 32x32x2 MFMA); one co-tile per wave halves that chain at twice the workgroups (bit-identical: the order over K is unchanged)
+        // short sequences (the T_w ~ 27 encoder, B = 1): bound by the serial fp32 MFMA chain of one wave (64 cycles per 32x32x2 MFMA) and
+        // by round trips nothing hides -> conv1d_short_kernel while the 32-row tile fits the LDS whole
         // (gated layers keep two co-tiles per wave: the tanh tile and its sigmoid partner meet in the epilogue)
-        // (FULL: the input tile is staged once for all its CK-chunks, while the rows fit the LDS)
-        const bool full = p.C_in_pad > CK && ((size_t)(31 * p.stride + (p.K - 1) * p.dil + 1) * (p.C_in_pad * 4 + 16) <= 150 * 1024);
-        if (p.T_out <= 64 && !p.gate_H) return full ? launch_cfg<ENGINE, 1, 1, 1, 4, CK, true>(p, stream) : launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);  // 32 t x 128 co
-        if (p.T_out <= 64) return full ? launch_cfg<ENGINE, 1, 2, 1, 4, CK, true>(p, stream) : launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);   // 32 t x 256 co
-        return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                      // 128 t x 64 co
+        if (p.T_out <= 64 && short_lds(p, 4, 1, 0) <= 150 * 1024) {
+            if (p.gate_H) return launch_short<ENGINE, 2, 4, 1>(p, stream);                           // 32 t x 256 co
+            // split the contraction over the workgroup's waves (each output tile's chain 2x / 4x shorter, 2x / 4x the workgroups) as far
+            // as ALL workgroups stay co-resident: a second round of workgroups costs more than the shorter chains give
+            static const int ks_env = [] { const char* e = getenv("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
+            const int n_cu = cu_count();
+            const int NG = p.C_in_pad / 8;
+            const size_t lds = short_lds(p, 4, 1, 0), per_cu_lds = (160 * 1024) / lds;
+            const bool wide = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4) > 256 * 8;
+            const size_t tiles = (size_t)((p.T_out + 31) / 32) * p.B;
+            int ks = 1;
+            for (int k = 4; k >= 2 && ks == 1; k >>= 1) {
+                if (NG % k) continue;
+                const size_t occ = wide ? 2 : (k == 4 ? 3 : 4);                    // waves per SIMD the kernel's registers allow
+                const size_t wgs = tiles * ((p.C_out_pad + 32 * (4 / k) - 1) / (32 * (4 / k)));
+                if (wgs <= (size_t)n_cu * (occ < per_cu_lds ? occ : per_cu_lds)) ks = k;
+            }
+            if (ks_env == 1 || ks_env == 2 || ks_env == 4) ks = (NG % ks_env == 0) ? ks_env : 1;
+            if (ks == 4) return launch_short<ENGINE, 1, 1, 4>(p, stream);         // 32 t x 32 co, contraction in 4
+            if (ks == 2) return launch_short<ENGINE, 1, 2, 2>(p, stream);         // 32 t x 64 co, contraction in 2
+            return launch_short<ENGINE, 1, 4, 1>(p, stream);                      // 32 t x 128 co
+        }
+        if (p.T_out <= 64 && !p.gate_H) return launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);   // 32 t x 128 co
+        if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);                // 32 t x 256 co
+        return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                                    // 128 t x 64 co
     } else {
         if (L.C_out_pad <= 32) return launch_cfg<ENGINE, 2, 1, 4, 1, CK>(p, stream);   // 256 t x 32 co
         if (L.C_out_pad <= 64) return launch_cfg<ENGINE, 2, 2, 4, 1, CK>(p, stream);   // 256 t x 64 co

@@ -779,6 +779,33 @@ def test_fft_blocks_long_batch_vs_oracle_and_missing_weight():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 40, 320])
+def test_fft_blocks_short_sequences_every_contraction_split(B):
+    """conv1d_short_kernel (T <= 64: the word encoder, B = 1): the launcher splits each output tile's contraction over 4, 2 or 1 waves
+    depending on how many workgroups the layer makes (B = 1 / 3 -> 4-way everywhere, B = 40 -> 2-way for the wide layers, B = 320 -> no
+    split for them), partial sums meeting in LDS in a fixed order.  Ragged lengths around the 32-row tile edge (1, 31, 32, 33, 64), a tile
+    entirely beyond its utterance, against the oracle; and bit-repeatable."""
+    from oracle import fft_blocks_ref as fref
+    from dict_tts_amd import fft
+    cfg = gc.G8_CASES["enc"]
+    sd = synth.fft_blocks_state_dict(gc.SEED + 2, 192, **cfg)
+    m = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=cfg["kernel_size"], num_heads=2, use_pos_embed=cfg["use_pos_embed"],
+                      use_last_norm=cfg["use_last_norm"], hparams={})
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    x = synth.randn(gc.SEED, f"fft.short.x{B}", (B, 64, 192), 1.0)
+    lens = [(64, 33, 32, 31, 1, 47, 17)[b % 7] for b in range(B)]
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    want = fref.fft_blocks({k: T(v) for k, v in sd.items()}, T(x), num_heads=2, kernel_size=cfg["kernel_size"],
+                           use_pos_embed=cfg["use_pos_embed"], use_last_norm=cfg["use_last_norm"])
+    got = m(T(x)).cpu()
+    assert (got - want).abs().max() <= 1e-4, float((got - want).abs().max())
+    for b, n in enumerate(lens):
+        assert not (got[b, n:] != 0).any()
+    assert torch.equal(m(T(x)).cpu(), got)
+
+
+@pytest.mark.gpu
 def test_abi_misuse_fails_loudly(voc_sd):
     """error convention of the C ABI: negative code + message, surfaced as abi.DttsError; no silent fallback"""
     from dict_tts_amd import hparams, model
@@ -873,7 +900,9 @@ def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
         T_mel = want["mel_out"].shape[1]
         got = _run(acoustic, batch, z=T(synth.noise(50 + k, 4, T_mel // 4)))
         assert torch.equal(got["mel2word"].cpu(), want["mel2word"]), k
-        assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-5
+        # log-durations of magnitude ~3 through four fp32 FFT blocks: summation-order noise (the short-sequence kernels split the
+        # contraction over waves) measures 3e-6 .. 1.4e-5 over these batches; the same 1e-4 bound as the golden-fixture tests
+        assert (got["dur"].cpu() - want["dur"]).abs().max() <= 1e-4
         assert (got["mel_out"].cpu() - want["mel_out"]).abs().max() <= 1e-3
 
 
