@@ -275,8 +275,38 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
                 }
             }
     }
-    if (engine == ENG_F32) L.w_hi = upload(h, wf);
-    else {
+    if (engine == ENG_F32) {
+        L.w_hi = upload(h, wf);
+        // + the same weights as three bf16 pieces in k-groups of 16 (conv1d.h: ENG_BF16X6) for the short-sequence kernel
+        if (!(h->tune & 131072) && L.C_in_pad % 16 == 0) {   // DTTS_TUNE bit 17: fp32 MFMA only
+            const int KG6 = 16, E6 = 8, NG6 = L.C_in_pad / KG6;
+            std::vector<uint16_t> pc[3];
+            for (auto& v : pc) v.assign(n, 0);
+            for (int pco = 0; pco < L.C_out_pad; ++pco) {
+                int co = pco;
+                if (gate_H) {
+                    const int tile = pco / 32, j = tile / 2, within = pco % 32;
+                    co = (tile & 1) ? gate_H + j * 32 + within : j * 32 + within;
+                    if (j * 32 + within >= gate_H) co = -1;
+                }
+                if (co < 0 || co >= C_out) continue;
+                const int ct = pco / 32, col = pco % 32;
+                for (int tap = 0; tap < K; ++tap)
+                    for (int ci = 0; ci < C_in; ++ci) {
+                        const int g = ci / KG6, within = ci % KG6, half = within / E6, e = within % E6;
+                        const size_t idx = ((((size_t)tap * NG6 + g) * NCT + ct) * 64 + half * 32 + col) * E6 + e;
+                        float r = getw(co, ci, tap);
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const uint16_t b16 = f2bf_host(r);
+                            pc[pl][idx] = b16;
+                            r -= bf2f_host(b16);   // exact: the remainder of a round-to-nearest bf16 fits fp32
+                        }
+                    }
+            }
+            for (int pl = 0; pl < 3; ++pl) L.x6[pl] = upload(h, pc[pl]);
+            if (!L.x6[0] || !L.x6[1] || !L.x6[2]) return false;
+        }
+    } else {
         L.w_hi = upload(h, whi);
         if (engine == ENG_BF16X3) L.w_lo = upload(h, wlo);
     }

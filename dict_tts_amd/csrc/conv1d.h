@@ -7,13 +7,16 @@
 //   ENG_F32   : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain — acoustic model, protects duration rounding)
 //   ENG_BF16  : v_mfma_f32_32x32x16_bf16 (vocoder, bf16 operands / fp32 accumulate)
 //   ENG_BF16X3: the same instruction on hi/lo split operands, 3 products (fp32-class vocoder mode)
+//   ENG_BF16X6: three bf16 pieces per operand (exact 24-bit split), the 6 products down to 2^-24: the fp32 MFMA's accuracy at 2.7x its
+//               rate (gfx950 has no xf32) — conv1d_short_kernel's form of the ENG_F32 layers
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace dtts {
 
-enum Engine { ENG_F32 = 0, ENG_BF16 = 1, ENG_BF16X3 = 2, ENG_F16 = 3 };   // ENG_F16: packed for the fused vocoder kernels only (vpair / rblock)
+enum Engine { ENG_F32 = 0, ENG_BF16 = 1, ENG_BF16X3 = 2, ENG_F16 = 3, ENG_BF16X6 = 4 };   // ENG_F16: packed for the fused vocoder kernels only (vpair / rblock);
+                                                                                        // ENG_BF16X6: the short-sequence kernel's form of an ENG_F32 layer (PackedConv::x6)
 
 // One output segment of the epilogue: y[b][t][coff + c] = ((acc + bias) + res + res2) / div
 struct ConvSeg {
@@ -29,7 +32,8 @@ struct ConvParams {
     int ldx, x_coff;
     long long x_bstride; // elements between batch items
     const void* w_hi;    // packed weights (fragment order), fp32 or bf16
-    const void* w_lo;    // bf16x3 only
+    const void* w_lo;    // bf16x3 / bf16x6: second piece
+    const void* w_lo2;   // bf16x6: third piece
     const float* bias;   // [C_out] logical order, may be null
     const int* in_lens;  // [B] valid input rows (rows >= len read as zero); null -> T_in
     const int* out_lens; // [B] valid output rows; null -> T_out
@@ -55,6 +59,7 @@ struct ConvParams {
 struct PackedConv {
     void* w_hi = nullptr;
     void* w_lo = nullptr;
+    void* x6[3] = {nullptr, nullptr, nullptr};   // ENG_F32 layers: the same weights as three bf16 pieces (k-groups of 16) for conv1d_short_kernel
     float* bias = nullptr;
     int engine = ENG_F32;
     int C_in = 0, C_in_pad = 0, C_out = 0, C_out_pad = 0, K = 1, CK = 64;

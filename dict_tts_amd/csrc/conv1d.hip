@@ -249,7 +249,7 @@ extern "C" int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMe
 #define STAMP(i)
 #endif
 template <int ENGINE, int NT, int WC, int KS, int U>
-__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1 : 2) : 3) void conv1d_short_kernel(const ConvParams p) {
     constexpr int MT = 1, WT = 1;   // one 32-row time tile per workgroup
     static_assert(WC * KS == 4, "four waves: co-tile groups x contraction splits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
 #endif
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
     constexpr int KG = (ENGINE == ENG_F32) ? 8 : 16;  // channels per k-group (one 16-B fragment per lane)
+    // operand planes: fp32 values as they are, or bf16 pieces x = p0 + p1 (+ p2), p_i = bf16(x - p_0 - .. - p_{i-1}) (exact remainders)
+    constexpr int NP = ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1;
     constexpr int TT = 32 * MT * WT;
     constexpr int CO_T = 32 * NT * WC;
 
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
     const int in0 = t0 * p.stride - p.pad;
     const int NG = p.C_in_pad / KG;
     const int pitch = p.C_in_pad * ES + 16;   // +16 B: conflict-free ds_read_b128 across 16 rows ((C_in_pad * ES + 16) mod 256 == 16 for the widths in use)
-    char* lds_lo = smem + (size_t)rows * pitch;
+    const int plane = rows * pitch;   // bytes between the planes of the staged tile
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -333,12 +335,11 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
                 if constexpr (ENGINE == ENG_F32) {
                     *(f32x4*)(smem + r * pitch + c4 * 16) = v;
                 } else {
-                    unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
-                    *(uint2*)(smem + r * pitch + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                    if constexpr (ENGINE == ENG_BF16X3) {
-                        unsigned l0 = f2bf(v[0] - bf2f(h0)), l1 = f2bf(v[1] - bf2f(h1));
-                        unsigned l2 = f2bf(v[2] - bf2f(h2)), l3 = f2bf(v[3] - bf2f(h3));
-                        *(uint2*)(lds_lo + r * pitch + c4 * 8) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const unsigned h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+                        *(uint2*)(smem + pl * plane + r * pitch + c4 * 8) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        v = f32x4{v[0] - bf2f(h0), v[1] - bf2f(h1), v[2] - bf2f(h2), v[3] - bf2f(h3)};
                     }
                 }
             }
@@ -395,28 +396,27 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
 #pragma unroll
         for (int n = 0; n < NT; ++n) epi_fetch(m, n, early[m][n]);
     STAMP(1)
-    // one step's MFMAs: weight fragments bh/bl x activation fragments ah/al into every (m, n) accumulator
-    auto mma = [&](const uint4 (&bh)[NT], const uint4 (&bl)[NT], const uint4 (&ah)[MT], const uint4 (&al)[MT]) {
+    // one step's MFMAs: weight fragments bw[plane][n] x activation fragments aw[plane][m] into every (m, n) accumulator.  Split
+    // operands: every product of pieces i, j with i + j < NP, smallest first (x3: 3 products ~ 2^-16; x6: 6 products ~ 2^-24, the
+    // fp32 MFMA's accuracy at 6 x 8 passes per 16 channels instead of 8 x 16)
+    auto mma = [&](const uint4 (&bw)[NP][NT], const uint4 (&aw)[NP][MT]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 // (a co-tile past the layer's last one computes on a clamped copy; the epilogue drops it)
                 if constexpr (ENGINE == ENG_F32) {
-                    const f32x4 a = *(const f32x4*)&ah[m];
-                    const f32x4 w = *(const f32x4*)&bh[n];
+                    const f32x4 a = *(const f32x4*)&aw[0][m];
+                    const f32x4 w = *(const f32x4*)&bw[0][n];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], w[q], acc[m][n], 0, 0, 0);
                 } else {
-                    const bf16x8 a = *(const bf16x8*)&ah[m];
-                    const bf16x8 w = *(const bf16x8*)&bh[n];
-                    if constexpr (ENGINE == ENG_BF16X3) {
-                        const bf16x8 a2 = *(const bf16x8*)&al[m];
-                        const bf16x8 w2 = *(const bf16x8*)&bl[n];
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, acc[m][n], 0, 0, 0);
-                    }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int d = NP - 1; d >= 0; --d)
+#pragma unroll
+                        for (int i = d; i >= 0; --i) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&aw[i][m], *(const bf16x8*)&bw[d - i][n], acc[m][n], 0, 0, 0);
+                        }
                 }
             }
     };
@@ -429,20 +429,19 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
         const int NGW = NG / KS;                      // k-groups per tap and wave (the launcher checks NG % KS == 0)
         const int S = p.K * NGW;
         const int kg_stride_i = NCT * 64, tap_wrap_w = (NG - NGW) * NCT * 64;
-        const uint4* wh = (const uint4*)p.w_hi + (size_t)ks * NGW * NCT * 64 + lane;
-        const uint4* wl = (const uint4*)p.w_lo + (size_t)ks * NGW * NCT * 64 + lane;
+        const uint4* wp[3] = {(const uint4*)p.w_hi + (size_t)ks * NGW * NCT * 64 + lane, (const uint4*)p.w_lo + (size_t)ks * NGW * NCT * 64 + lane,
+                              (const uint4*)p.w_lo2 + (size_t)ks * NGW * NCT * 64 + lane};
         int ctc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) ctc[n] = ct0 + n < NCT ? ct0 + n : NCT - 1;
         // two cursors over the wave's step sequence (weights run PF steps ahead, activations one), advanced by adds; both stop on
         // the last step
         int wo = 0, wg = 0, ws = 0;
-        auto load_w = [&](uint4 (&dh)[NT], uint4 (&dl)[NT]) {
+        auto load_w = [&](uint4 (&d)[NP][NT]) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                dh[n] = wh[wo + ctc[n] * 64];
-                if constexpr (ENGINE == ENG_BF16X3) dl[n] = wl[wo + ctc[n] * 64];
-            }
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) d[pl][n] = wp[pl][wo + ctc[n] * 64];
             if (ws + 1 < S) {
                 ++ws;
                 wo += kg_stride_i;
@@ -455,12 +454,11 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
         const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + ks * NGW * KG * ES;
         const int tap_wrap_x = p.dil * pitch - NGW * KG * ES;
         int xo = 0, xg = 0, xs = 0;
-        auto load_x = [&](uint4 (&dh)[MT], uint4 (&dl)[MT]) {
+        auto load_x = [&](uint4 (&d)[NP][MT]) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                dh[m] = *(const uint4*)(smem + abase + xo + m * 32 * p.stride * pitch);
-                if constexpr (ENGINE == ENG_BF16X3) dl[m] = *(const uint4*)(lds_lo + abase + xo + m * 32 * p.stride * pitch);
-            }
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) d[pl][m] = *(const uint4*)(smem + pl * plane + abase + xo + m * 32 * p.stride * pitch);
             if (xs + 1 < S) {
                 ++xs;
                 xo += KG * ES;
@@ -470,17 +468,17 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? 2 : 3) void conv1d_short_
                 }
             }
         };
-        uint4 rh[R][NT], rl[R][NT], xh[2][MT], xl[2][MT];
+        uint4 rw[R][NP][NT], xa[2][NP][MT];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) load_w(rh[j], rl[j]);
-        load_x(xh[0], xl[0]);
+        for (int j = 0; j < PF; ++j) load_w(rw[j]);
+        load_x(xa[0]);
         for (int s = 0; s < S; s += R) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                load_w(rh[(j + PF) % R], rl[(j + PF) % R]);
-                load_x(xh[(j + 1) & 1], xl[(j + 1) & 1]);
+                load_w(rw[(j + PF) % R]);
+                load_x(xa[(j + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s + j < S) mma(rh[j], rl[j], xh[j & 1], xl[j & 1]);
+                if (s + j < S) mma(rw[j], xa[j & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -626,7 +624,7 @@ template <int ENGINE, int NT, int WC, int KS, int U>
 static hipError_t launch_short_u(const ConvParams& p, hipStream_t stream) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
     constexpr size_t LDS_CU = 160 * 1024;
-    const size_t lds = short_lds(p, ES, ENGINE == ENG_BF16X3 ? 2 : 1, (KS - 1) * WC * NT);
+    const size_t lds = short_lds(p, ES, ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1, (KS - 1) * WC * NT);
     auto kern = conv1d_short_kernel<ENGINE, NT, WC, KS, U>;
     static bool configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
     int cur_dev = 0;
@@ -649,34 +647,52 @@ static hipError_t launch_short(const ConvParams& p, hipStream_t stream) {
     return pieces <= 256 * 8 ? launch_short_u<ENGINE, NT, WC, KS, 8>(p, stream) : launch_short_u<ENGINE, NT, WC, KS, 24>(p, stream);
 }
 
+// Short sequences (the T_w ~ 27 encoder, B = 1): bound by the serial MFMA chain of one wave and by round trips nothing hides ->
+// conv1d_short_kernel while the 32-row tile fits the LDS whole.  (Gated layers keep two co-tiles per wave: the tanh tile and its
+// sigmoid partner meet in the epilogue.)  Returns false when the layer does not qualify.
+template <int ENGINE>
+static bool launch_short_policy(const ConvParams& p, hipStream_t stream, hipError_t* err) {
+    constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2, KG = (ENGINE == ENG_F32) ? 8 : 16, NP = ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1;
+    const size_t lds = short_lds(p, ES, NP, 0);
+    if (p.T_out > 64 || lds > 150 * 1024) return false;
+    if (p.gate_H) {
+        *err = launch_short<ENGINE, 2, 4, 1>(p, stream);                           // 32 t x 256 co
+        return true;
+    }
+    // split the contraction over the workgroup's waves (each output tile's chain 2x / 4x shorter, 2x / 4x the workgroups) as far
+    // as ALL workgroups stay co-resident: a second round of workgroups costs more than the shorter chains give
+    static const int ks_env = [] { const char* e = getenv("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
+    const int n_cu = cu_count();
+    const int NG = p.C_in_pad / KG;
+    const size_t per_cu_lds = (160 * 1024) / lds;
+    const bool wide = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4) > 256 * 8;
+    const size_t tiles = (size_t)((p.T_out + 31) / 32) * p.B;
+    int ks = 1;
+    for (int k = 4; k >= 2 && ks == 1; k >>= 1) {
+        if (NG % k) continue;
+        const size_t occ = wide ? 2 : (k == 4 ? 3 : (ENGINE == ENG_F32 ? 4 : 3));   // waves per SIMD the kernel's registers allow
+        const size_t wgs = tiles * ((p.C_out_pad + 32 * (4 / k) - 1) / (32 * (4 / k)));
+        if (wgs <= (size_t)n_cu * (occ < per_cu_lds ? occ : per_cu_lds)) ks = k;
+    }
+    if (ks_env == 1 || ks_env == 2 || ks_env == 4) ks = (NG % ks_env == 0) ? ks_env : 1;
+    if (ks == 4) *err = launch_short<ENGINE, 1, 1, 4>(p, stream);         // 32 t x 32 co, contraction in 4
+    else if (ks == 2) *err = launch_short<ENGINE, 1, 2, 2>(p, stream);    // 32 t x 64 co, contraction in 2
+    else *err = launch_short<ENGINE, 1, 4, 1>(p, stream);                 // 32 t x 128 co
+    return true;
+}
+
 template <int ENGINE, int CK>
 static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStream_t stream) {
     if constexpr (ENGINE == ENG_F32) {
-        // short sequences (the T_w ~ 27 encoder, B = 1): bound by the serial fp32 MFMA chain of one wave (64 cycles per 32x32x2 MFMA) and
-        // by round trips nothing hides -> conv1d_short_kernel while the 32-row tile fits the LDS whole
-        // (gated layers keep two co-tiles per wave: the tanh tile and its sigmoid partner meet in the epilogue)
-        if (p.T_out <= 64 && short_lds(p, 4, 1, 0) <= 150 * 1024) {
-            if (p.gate_H) return launch_short<ENGINE, 2, 4, 1>(p, stream);                           // 32 t x 256 co
-            // split the contraction over the workgroup's waves (each output tile's chain 2x / 4x shorter, 2x / 4x the workgroups) as far
-            // as ALL workgroups stay co-resident: a second round of workgroups costs more than the shorter chains give
-            static const int ks_env = [] { const char* e = getenv("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
-            const int n_cu = cu_count();
-            const int NG = p.C_in_pad / 8;
-            const size_t lds = short_lds(p, 4, 1, 0), per_cu_lds = (160 * 1024) / lds;
-            const bool wide = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4) > 256 * 8;
-            const size_t tiles = (size_t)((p.T_out + 31) / 32) * p.B;
-            int ks = 1;
-            for (int k = 4; k >= 2 && ks == 1; k >>= 1) {
-                if (NG % k) continue;
-                const size_t occ = wide ? 2 : (k == 4 ? 3 : 4);                    // waves per SIMD the kernel's registers allow
-                const size_t wgs = tiles * ((p.C_out_pad + 32 * (4 / k) - 1) / (32 * (4 / k)));
-                if (wgs <= (size_t)n_cu * (occ < per_cu_lds ? occ : per_cu_lds)) ks = k;
-            }
-            if (ks_env == 1 || ks_env == 2 || ks_env == 4) ks = (NG % ks_env == 0) ? ks_env : 1;
-            if (ks == 4) return launch_short<ENGINE, 1, 1, 4>(p, stream);         // 32 t x 32 co, contraction in 4
-            if (ks == 2) return launch_short<ENGINE, 1, 2, 2>(p, stream);         // 32 t x 64 co, contraction in 2
-            return launch_short<ENGINE, 1, 4, 1>(p, stream);                      // 32 t x 128 co
+        hipError_t err = hipSuccess;
+        if (L.x6[0]) {   // the same weights as three bf16 pieces: fp32-grade products at 2.7x the fp32 MFMA rate
+            ConvParams q = p;
+            q.w_hi = L.x6[0];
+            q.w_lo = L.x6[1];
+            q.w_lo2 = L.x6[2];
+            if (launch_short_policy<ENG_BF16X6>(q, stream, &err)) return err;
         }
+        if (launch_short_policy<ENG_F32>(p, stream, &err)) return err;
         if (p.T_out <= 64 && !p.gate_H) return launch_cfg<ENGINE, 1, 1, 1, 4, CK>(p, stream);   // 32 t x 128 co
         if (p.T_out <= 64) return launch_cfg<ENGINE, 1, 2, 1, 4, CK>(p, stream);                // 32 t x 256 co
         return launch_cfg<ENGINE, 1, 2, 4, 1, CK>(p, stream);                                    // 128 t x 64 co
@@ -691,6 +707,7 @@ static hipError_t launch_engine(const PackedConv& L, const ConvParams& p, hipStr
 hipError_t conv1d_launch(const PackedConv& L, ConvParams p, hipStream_t stream) {
     p.w_hi = L.w_hi;
     p.w_lo = L.w_lo;
+    p.w_lo2 = nullptr;
     p.bias = L.bias;
     p.C_in = L.C_in;
     p.C_in_pad = L.C_in_pad;
