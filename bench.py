@@ -493,11 +493,12 @@ def main():
         a2_flop = 8.0 * (2_064_384 + 768 * hb["T_w"]) * hb["B"] * hb["T_w"]
         if ref_names["dict_encoder"] > 0:
             a2_tf = a2_flop / (ref_names["dict_encoder"] * 1e-3) / 1e12
-            stages["encoder_blocks_roofline"] = {"bound": "mfma (fp32: exact fma chains keep the integer durations)", "achieved": a2_tf, "peak": 157.3,
+            stages["encoder_blocks_roofline"] = {"bound": "mfma (fp32-grade arithmetic keeps the integer durations: bf16 three-piece operands, 6 MFMA products; peak = the fp32 matrix rate BASELINE.md names, the 6-product form's own ceiling is 2500 / 6 = 417)", "achieved": a2_tf, "peak": 157.3,
                                                  "unit": "TFLOP/s", "frac": a2_tf / 157.3, "span_ms": ref_names["dict_encoder"],
                                                  "flop": a2_flop, "padded_word_tokens": hb["B"] * hb["T_w"],
-                                                 "note": "A2 rows of SURVEY 8a over the padded batch; ~90 launches of 5-45 us: launch / latency and "
-                                                         "SIMD-imbalance bound (60 utterances x 32-row tiles on 1024 SIMDs), not MFMA bound"}
+                                                 "note": "A2 rows of SURVEY 8a over the padded batch; ~90 launches of 5-25 us bound by per-kernel round trips "
+                                                         "(staging 3-4 us, epilogue 1-1.5 us) and one wave's MFMA chain (60 utterances x 32-row tiles; "
+                                                         "tools/c1d_phase_prof.py), not by the matrix rate"}
         # how often the round() discontinuity of add_dur (model.py:78) is in play: words of the GPU's own dur within 5e-5 of a .5 tie
         dur_t = torch.empty(hb["B"], hb["T_w"], device=dev)
         m.ctx.fetch(abi.OUT_DUR, dur_t.data_ptr(), stream)
@@ -561,7 +562,7 @@ def main():
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.workload == "rotating" else "strong", "vs_baseline": None,
-            "dtype": {"f16": "f16 (vocoder ResBlocks fp16 MFMA, serial convolutions bf16 hi/lo split; acoustic model fp32 MFMA)",
+            "dtype": {"f16": "f16 (vocoder ResBlocks fp16 MFMA, serial convolutions bf16 hi/lo split; acoustic model fp32-grade: fp32 MFMA / bf16 three-piece operands x 6 products)",
                       "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision],
             "data": "synthetic (random-init weights of the real architecture, Biaobei sentence/dictionary structure)",
             "config": {"workload": ("BASELINE configs[1]: Biaobei batch=60 per GPU, full Dict-TTS encoder + FVAE decoder + HifiGAN, predicted "
@@ -580,7 +581,7 @@ def main():
                                          "tensors": "reference API: keys/values tensors uploaded per step + int16 waveform D2H"}[args.input],
                        "parallelism": f"dp{world}" + ("+allgather(mel)" if gather_on else ""),
                        "streams": "2 (vocoder of batch i overlaps text->mel of batch i+1)" if pipelined else "1",
-                       "acoustic_dtype": "f32 (fp32 MFMA)", "vocoder_dtype": args.precision},
+                       "acoustic_dtype": "f32-grade (fp32 MFMA; word-encoder convolutions as 3 bf16 pieces x 6 products)", "vocoder_dtype": args.precision},
             "audio_samples_per_sec": samples, "rtf": 22050.0 / samples,
             "mel_allgather": gather_info,
             "ranks_seen": seen, "distinct_devices": (len({(r["device_index"], r["device_uuid"]) for r in seen}) if seen else 1),
