@@ -461,7 +461,25 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
     // k = 11 tile instead of 23 %; -8 % on that launch), k = 3 on 512-row tiles, two 4-wave workgroups per CU, one tile each (the
     // 1024-row form is 14 % slower there).  DTTS_RB32=0: 512-row tiles for every k (round 2).
     static const int rb32 = getenv("DTTS_RB32") ? atoi(getenv("DTTS_RB32")) : 1;
-    if (C == 32 && rb32 && p.K >= 7) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
+    // small batches (B = 1: one sentence): when the default tiles leave more than half of the CUs without one, the launch takes as long
+    // as ONE tile -> half-size tiles (more halo recomputed, but twice the CUs at work)
+    static const bool small_ok = [] { const char* e = getenv("DTTS_RB_SMALL"); return !e || atoi(e) != 0; }();
+    static int cus_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    int& cus = cus_dev[cur_dev & 63];
+    if (!cus) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, cur_dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    auto few = [&](int W) {   // tiles of W rows (valid: W - 12 (k - 1), the fused conv_post 6 less): at most half the CUs get one
+        const int tt = W - 12 * (p.K - 1) - (p.wav ? 6 : 0);
+        return small_ok && tt >= 32 && 2 * (long long)p.B * ((p.T + tt - 1) / tt) <= cus;
+    };
+    if (C == 32 && rb32 && p.K >= 7 && !few(1024)) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
+    if (C == 64 && few(512)) return rb_launch_cfg<64, 4, 1, 2, 2, EL, 1>(p, stream);     // 256-row tile, 4 waves
+    if (C == 128 && few(256)) return rb_launch_cfg<128, 4, 1, 1, 4, EL, 1>(p, stream);   // 128-row tile, 4 waves
+    if (C == 256 && few(128)) return rb_launch_cfg<256, 2, 1, 1, 8, EL, 1>(p, stream);   // 64-row tile
     if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1, EL, 0>(p, stream);      // 512-row tile, 4 waves over time
     if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
     if (C == 128) return rb_launch_cfg<128, 4, 1, 2, 4, EL, 1>(p, stream);    // 256-row tile, 8 waves (2 time x 4 channel)

@@ -24,7 +24,7 @@ template <int C, int TT, int EL, bool GUARD>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = (TT == 192 || TT == 96) ? 3 : 4, NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
+    constexpr int MT = (TT == 192 || TT == 96) ? 3 : (TT == 64 ? 2 : 4), NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
@@ -326,9 +326,27 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
 #ifndef VP_TT96
 #define VP_TT96 1
 #endif
+// CUs of the current device (cached per device)
+static int vpair_cus() {
+    static int cus_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    int& cus = cus_dev[cur_dev & 63];
+    if (!cus) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, cur_dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 template <int EL>
 static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t stream) {
+    // small batches (B = 1: one sentence): the default tiles would leave most CUs without one and the launch takes as long as ONE tile
+    // -> half-size tiles (more halo rows recomputed, twice the weight stream per row, but twice the CUs at work)
+    static const bool small_ok = [] { const char* e = getenv("DTTS_VP_SMALL"); return !e || atoi(e) != 0; }();
+    auto tiles_of = [&](int tt) { return (long long)p.B * ((p.T + (tt - (p.K - 1)) - 1) / (tt - (p.K - 1))); };
     if (C == 256) {
+        if (small_ok && 2 * tiles_of(128) <= vpair_cus()) return vpair_launch_tt<256, 64, EL>(p, stream);
         // 128-row tiles, or 96-row ones where only those leave room for TWO workgroups per CU (one workgroup = one wave per SIMD exposes
         // every latency of the memory phases: k = 7 with dilation 5, k = 11 with dilation 3)
         auto lds_of = [&](int tt) { return ((size_t)tt + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 4)) * (256 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int); };
@@ -338,6 +356,7 @@ static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t strea
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
     const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
+    if (small_ok && 2 * tiles_of(256) <= vpair_cus()) return vpair_launch_tt<128, 128, EL>(p, stream);
     if (big) return vpair_launch_tt<128, 256, EL>(p, stream);
     // k = 11 with dilation 5: 192-row tiles (two workgroups per CU, persistent) instead of 128-row ones (three, one tile each)
     return vpair_launch_tt<128, 192, EL>(p, stream);
