@@ -647,14 +647,14 @@ static hipError_t launch_short(const ConvParams& p, hipStream_t stream) {
     return pieces <= 256 * 8 ? launch_short_u<ENGINE, NT, WC, KS, 8>(p, stream) : launch_short_u<ENGINE, NT, WC, KS, 24>(p, stream);
 }
 
-// Short sequences (the T_w ~ 27 encoder, B = 1): bound by the serial MFMA chain of one wave and by round trips nothing hides ->
-// conv1d_short_kernel while the 32-row tile fits the LDS whole.  (Gated layers keep two co-tiles per wave: the tanh tile and its
+// Few rows (the T_w ~ 27 encoder at B = 60, one long text at B = 1: <= 256 tiles of 32 rows): bound by the serial MFMA chain of one wave
+// and by round trips nothing hides -> conv1d_short_kernel while the 32-row tile fits the LDS whole.  (Gated layers keep two co-tiles per wave: the tanh tile and its
 // sigmoid partner meet in the epilogue.)  Returns false when the layer does not qualify.
 template <int ENGINE>
 static bool launch_short_policy(const ConvParams& p, hipStream_t stream, hipError_t* err) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2, KG = (ENGINE == ENG_F32) ? 8 : 16, NP = ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1;
     const size_t lds = short_lds(p, ES, NP, 0);
-    if (p.T_out > 64 || lds > 150 * 1024) return false;
+    if ((long long)p.B * ((p.T_out + 31) / 32) > 256 || lds > 150 * 1024) return false;
     if (p.gate_H) {
         *err = launch_short<ENGINE, 2, 4, 1>(p, stream);                           // 32 t x 256 co
         return true;

@@ -304,9 +304,180 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* qkv, float* 
     }
 }
 
+// ---- the same kernel for FEW, LONG sequences (one 1000-character text at B = 1: 8 x 2 workgroups of the form above, each walking
+// all 32 key tiles one after the other): a workgroup takes ONE tile of 32 queries and its four waves split the keys — 128 keys are
+// staged per round, wave w attends to keys 32 w .. 32 w + 31 of the round — and the four partial (max, sum, O) triples are merged
+// once at the end (the flash-decoding reduction, fixed order w = 0..3).  4x the workgroups, 1/4 of the serial chain per wave.
+__global__ __launch_bounds__(256) void mha_mfma_split_kernel(const float* qkv, float* out, const int* lens, int T, int C) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    constexpr int DK = MHX_DK, TILE = MHX_KT * MHX_PITCH;
+    char* ks_all = dyn;                          // [4][32 rows]
+    char* vs_all = dyn + 4 * TILE;               // [4][32 rows]
+    float (*bc)[32] = (float (*)[32])(dyn + 8 * TILE);   // per-wave broadcast of a per-query scalar; later the merge's statistics
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
+    const int len = lens ? min(max(lens[b], 0), T) : T;
+    const float* base = qkv + (long long)b * T * 3 * C + h * DK;
+    float* ob = out + (long long)b * T * C + h * DK;
+    if (q0 >= len) {   // a tile of padded queries: every caller masks these rows
+        for (int idx = tid; idx < 32 * (DK / 4); idx += 256) {
+            const int i = idx / (DK / 4), c4 = idx % (DK / 4);
+            if (q0 + i < T) *(f32x4*)(ob + (long long)(q0 + i) * C + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const float inv_sqrt = 1.0f / sqrtf((float)DK);
+    const int q = q0 + x;                        // this lane's query (the same 32 queries in every wave)
+    f32x4 qf[DK / 8];
+#pragma unroll
+    for (int g = 0; g < DK / 8; ++g)
+        qf[g] = q < len ? *(const f32x4*)(base + (long long)q * 3 * C + 8 * g + 4 * hf) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16m o[DK / 32];
+#pragma unroll
+    for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const char* ks = ks_all + wave * TILE;
+    const char* vs = vs_all + wave * TILE;
+    for (int j00 = 0; j00 < len; j00 += 4 * MHX_KT) {
+        __syncthreads();
+        for (int idx = tid; idx < 4 * MHX_KT * (DK / 4); idx += 256) {   // K / V rows of this round (128 keys), zeros past the end
+            const int j = idx / (DK / 4), c4 = idx % (DK / 4);
+            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (j00 + j < len) {
+                const float* r = base + (long long)(j00 + j) * 3 * C + c4 * 4;
+                kv = *(const f32x4*)(r + C);
+                vv = *(const f32x4*)(r + 2 * C);
+            }
+            *(f32x4*)(ks_all + j * MHX_PITCH + c4 * 16) = kv;
+            *(f32x4*)(vs_all + j * MHX_PITCH + c4 * 16) = vv;
+        }
+        __syncthreads();
+        const int j0 = j00 + wave * MHX_KT;
+        if (j0 >= len) continue;                 // (uniform per wave; the barriers above are outside)
+        f32x16m st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < DK / 8; ++g) {
+            const f32x4 kf = *(const f32x4*)(ks + x * MHX_PITCH + (8 * g + 4 * hf) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], st, 0, 0, 0);
+        }
+        float tmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            float sv = st[r] * inv_sqrt;
+            if (!(q < len && j < len)) sv = -1e4f;
+            st[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(st[r] - mn);
+            st[r] = pv;
+            ps += pv;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = mn;
+        if (hf == 0) bc[wave][x] = alpha;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 al = *(const f32x4*)&bc[wave][8 * r4 + 4 * hf];
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[dt][4 * r4 + e] *= al[e];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = (r & 3) + 8 * (r >> 2) + 4 * hf;
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt) {
+                const float vv = *(const float*)(vs + jl * MHX_PITCH + (dt * 32 + x) * 4);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vv, o[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // bc is rewritten next round
+    }
+    // ---- merge: M = max_w m_w ; every wave scales its O and l by exp(m_w - M) ; waves 1..3 hand theirs to wave 0 through LDS
+    __syncthreads();                             // the K / V tiles are dead: their LDS takes the partial sums
+    float* mstat = (float*)(dyn + 8 * TILE);     // [4][32] maxima, then [4][32] scaled sums behind them
+    if (hf == 0) mstat[wave * 32 + x] = m_run;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(mstat[x], mstat[32 + x]), fmaxf(mstat[64 + x], mstat[96 + x]));
+    const float sc = expf(m_run - M);            // (a wave that saw no key: m = -1e30 -> 0)
+    __syncthreads();                             // every wave has read the maxima
+    if (hf == 0) {
+        mstat[wave * 32 + x] = sc;               // this wave's per-query scale (crosses lanes like alpha above)
+        mstat[128 + wave * 32 + x] = l_run * sc;
+    }
+    __syncthreads();
+    float* part = (float*)dyn;                   // [3 waves][DK / 32][16][64]
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 al = *(const f32x4*)&mstat[wave * 32 + 8 * r4 + 4 * hf];
+#pragma unroll
+        for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[dt][4 * r4 + e] *= al[e];
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(((wave - 1) * (DK / 32) + dt) * 16 + r) * 64 + lane] = o[dt][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] += part[(((w - 1) * (DK / 32) + dt) * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qq = 8 * r4 + 4 * hf + e;  // query of accumulator register 4 r4 + e
+            const int qi = q0 + qq;
+            if (qi >= T) continue;
+            const float lsum = ((mstat[128 + qq] + mstat[160 + qq]) + mstat[192 + qq]) + mstat[224 + qq];
+            const float il = 1.0f / lsum;
+#pragma unroll
+            for (int dt = 0; dt < DK / 32; ++dt) ob[(long long)qi * C + dt * 32 + x] = o[dt][4 * r4 + e] * il;
+        }
+    }
+}
+
 hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int T, int C, int heads, hipStream_t s) {
     const int dk = C / heads;
     if (dk == MHX_DK) {
+        // few long sequences: keys split over the waves (see mha_mfma_split_kernel) while the 128-query form would fill < half the CUs
+        static const bool split_ok = [] { const char* e = getenv("DTTS_MHA_SPLIT"); return !e || atoi(e) != 0; }();
+        if (split_ok && T > 128 && (long long)((T + 127) / 128) * heads * B <= 128) {
+            constexpr int LDS = 8 * MHX_KT * MHX_PITCH + 8 * 32 * (int)sizeof(float);
+            static bool configured_dev[64] = {};
+            int cur_dev = 0;
+            (void)hipGetDevice(&cur_dev);
+            if (!configured_dev[cur_dev & 63]) {
+                hipError_t e = hipFuncSetAttribute((const void*)mha_mfma_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                if (e != hipSuccess) return e;
+                configured_dev[cur_dev & 63] = true;
+            }
+            hipLaunchKernelGGL(mha_mfma_split_kernel, dim3((T + 31) / 32, heads, B), dim3(256), LDS, s, qkv, out, lens, T, C);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(mha_mfma_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, lens, T, C);
         return hipGetLastError();
     }
