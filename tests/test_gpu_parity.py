@@ -779,6 +779,31 @@ def test_fft_blocks_long_batch_vs_oracle_and_missing_weight():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_utt", [2, 24])
+def test_exact_fp32_decoder_configuration(oracle_sd, n_utt):
+    """dtts_config.decoder_fp32 = 1: prior flow, conditioning, g_pre_net and the decoder WaveNet on the fp32-grade engines instead of the
+    split-bf16 ones — the GATED form of the convolution kernels (tanh * sigmoid epilogue, two co-tiles per wave): 2 utterances run the
+    few-row kernel (conv1d_short_kernel, gated, three-piece bf16 products), 24 utterances the generic one.  Same gates as the default
+    configuration, and a tighter mel error than it (no 2^-16 products anywhere)."""
+    from dict_tts_amd import abi, hparams, model
+    from oracle import dict_tts_ref as ref
+    cfg = hparams.fill_abi_config(abi.default_config(), {}, None, n_phone=6)
+    cfg.decoder_fp32 = 1
+    m = model.PortaSpeech_dict(hparams={}, ctx=abi.Context(cfg))
+    m.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()}, strict=True)
+    st = synth.biaobei_struct()
+    batch = synth.make_batch(st["sentences"][:n_utt], 77)
+    b = {k: T(v) for k, v in batch.items()}
+    want = ref.forward_infer(oracle_sd, b["word_tokens"], (b["keys"], b["values"], b["key_map"], b["pinyin"], b["pinyin_map"]),
+                             b["pron_modified"], z_p=lambda B, T4: T(synth.noise(78, B, T4)))
+    T_mel = want["mel_out"].shape[1]
+    got = _run(m, batch, z=T(synth.noise(78, n_utt, T_mel // 4)))
+    assert torch.equal(got["mel2word"].cpu(), want["mel2word"])
+    err = float((got["mel_out"].cpu() - want["mel_out"]).abs().max())
+    assert err <= 1e-4, err   # the gate is 1e-3; the fp32-grade decoder measures ~1e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 3, 40, 320])
 def test_fft_blocks_short_sequences_every_contraction_split(B):
     """conv1d_short_kernel (T <= 64: the word encoder, B = 1): the launcher splits each output tile's contraction over 4, 2 or 1 waves
