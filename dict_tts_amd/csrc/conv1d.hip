@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv1d_short_kernel: the same convolution for FEW ROWS (<= 256 tiles of 32 output rows over the whole batch: the word encoders at
+// T_w ~ 27, the duration predictor, B = 1, one long text).  There the generic kernel is bound by per-kernel round trips and by one
+// wave's serial MFMA chain, not by the matrix rate (tools/c1d_phase_prof.py; LABNOTES (qq)-(ss)):
+//   * one 32-row tile per workgroup, staged WHOLE (all C_in) in one batch of loads; (tap, k-group) is one step sequence per wave;
+//   * KS = 2 / 4: the workgroup's waves each sum 1/KS of the k-groups of every tap, partial sums meet in LDS in a fixed order;
+//   * ENG_BF16X6: fp32-grade products from three bf16 pieces per operand (6 MFMAs per 16 channels instead of 8 fp32 ones per 8);
+//   * the epilogue's operands are requested above the contraction; every optional epilogue step runs over all 16 rows of the lane
+//     under one uniform branch.
+// C1D_PROF = 1 (make prof): per-workgroup cycle stamps at start / tile staged / contraction done / stores issued.
 #ifndef C1D_PROF
 #define C1D_PROF 0
 #endif
@@ -295,9 +305,10 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
     if (pslot >= 0 && threadIdx.x == 0) c1d_prof[pslot][pwg][5] = 1 + live;
 #endif
 
-    // ---- stage X[in0 .. in0+rows) x [0, C_in_pad) into LDS (pre-activation, zero padding, conversion): U independent 16 B loads in
-    // flight per thread (the launcher picks U so that the whole tile is ONE batch where the registers allow), then conversion + LDS writes.  The rows are requested before the utterance's length is known (up to the padded
-    // T_in, masked afterwards): kernel arguments -> lengths -> rows would be one more round trip with nothing to hide it.
+    // ---- stage X[in0 .. in0 + rows) x [0, C_in_pad) into LDS (pre-activation, zero padding, conversion / split into planes): U independent
+    // 16 B loads in flight per thread (the launcher picks U so that the whole tile is ONE batch where the registers allow), then the LDS
+    // writes.  The rows are requested before the utterance's length is known (up to the padded T_in, masked afterwards): kernel arguments
+    // -> lengths -> rows would be one more round trip with nothing to hide it.
     {
         const int PIECES = p.C_in_pad / 4;
         const int total = rows * PIECES;
