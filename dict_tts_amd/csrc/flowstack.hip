@@ -46,6 +46,8 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
     float* ab = hb + (W + 2) * HP;                      // [W][HP]
     float* wp = ab + W * HP;                            // pre / post weights of the current block: FS_PRE + FS_POST floats
     float* pm = wp + FS_PRE + FS_POST;                  // [W][FS_HALF]: channel half 1's partial sums of post()
+    float* rb = pm + W * FS_HALF;                       // [layers][2 * FS_H]: the current block's res_skip biases (an L2 round trip per layer otherwise)
+    float* ib = rb + p.layers * 2 * FS_H;               // [layers][2 * FS_H]: its in_layer biases
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int rt = wave & 3, ch = wave >> 2;
@@ -85,19 +87,20 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
         lo = make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
     };
 
-    // this lane's bias + conditioning of layer g = block * layers + layer (its row; tanh quad q of tile ch in [0][q], its sigmoid partner
-    // in [1][q]): the accumulators' initial value, fetched one layer ahead
+    // this lane's conditioning of layer g = block * layers + layer (its row; tanh quad q of tile ch in [0][q], its sigmoid partner in
+    // [1][q]), fetched one layer ahead as PLAIN loads — nothing consumes them before the next layer's accumulators are initialised
+    // (cond + in_layer bias from LDS), so the HBM round trip runs under the gate and the 1x1 convolution.  (Adding the bias here, as
+    // rounds 1-2 did, made every group of loads wait for its data on the spot: four serial round trips per layer.)
     fs4 cnd[2][4];
     auto load_cond = [&](int g) {
         if (g >= p.n_flows * p.layers) return;
-        const float* bin = p.w + (size_t)(g / p.layers) * fs_flow_floats(p.layers) + FS_PRE + (size_t)(g % p.layers) * FS_LAYER + FS_IN_FRAGS + c0;
         const float* cr = p.cond + grow * p.ld_cond + (size_t)g * 2 * FS_H + c0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                cnd[m][q] = *(const fs4*)(bin + 64 * m + 8 * q);
-                if (inb) cnd[m][q] += *(const fs4*)(cr + 64 * m + 8 * q);
+                cnd[m][q] = fs4{0.f, 0.f, 0.f, 0.f};
+                if (inb) cnd[m][q] = *(const fs4*)(cr + 64 * m + 8 * q);
             }
     };
     load_cond(0);
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
         __syncthreads();   // the previous block's readers of wp / hb / pm are done (and the z tile / guards are in place)
         for (int i = tid; i < (int)FS_PRE; i += 512) wp[i] = wf[i];
         for (int i = tid; i < (int)FS_POST; i += 512) wp[FS_PRE + i] = wf[FS_PRE + (size_t)p.layers * FS_LAYER + i];
+        for (int i = tid; i < p.layers * 2 * FS_H; i += 512)
+            rb[i] = wf[FS_PRE + (size_t)(i / (2 * FS_H)) * FS_LAYER + FS_IN_FRAGS + 2 * FS_H + FS_RS_FRAGS + i % (2 * FS_H)];
+        for (int i = tid; i < p.layers * 2 * FS_H; i += 512) ib[i] = wf[FS_PRE + (size_t)(i / (2 * FS_H)) * FS_LAYER + FS_IN_FRAGS + i % (2 * FS_H)];
         __syncthreads();
         // ---- h = pre(x0): this lane's 16 channels of its row
         {
@@ -131,20 +137,20 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
 #pragma unroll
         for (int i = 0; i < 16; ++i) skip[i] = 0.f;
         __syncthreads();
-
 #pragma unroll 1
         for (int l = 0; l < p.layers; ++l) {
             const float* wl = wf + FS_PRE + (size_t)l * FS_LAYER;
-            const float* brs = wl + FS_IN_FRAGS + 2 * FS_H + FS_RS_FRAGS;
             const bool last = l == p.layers - 1;
             // ---- x_in = in_layer(h) + bias + cond (tiles ch and ch + 2): the accumulators start at bias + cond
             fs16 acc[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    const fs4 bi = *(const fs4*)(ib + l * 2 * FS_H + 64 * m + c0 + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][4 * q + e] = cnd[m][q][e];
+                    for (int e = 0; e < 4; ++e) acc[m][4 * q + e] = bi[e] + cnd[m][q][e];
+                }
             if constexpr (X3) {
                 // fragment f = (tap * 4 + kb) * 4 + n: hi at uint4 index (2f) * 64 + lane, lo at (2f + 1) * 64 + lane; PFD steps ahead
                 constexpr int NIT = FS_K * (FS_H / 16), PFD = 3;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
                     bv = bn;
                 }
             }
-            load_cond(f * p.layers + l + 1);   // the next layer's (or block's) bias + conditioning travel during the gate and the 1x1 convolution
+            load_cond(f * p.layers + l + 1);   // the next layer's (or block's) conditioning travels during the gate and the 1x1 convolution
             // ---- acts = tanh(x_in[:H]) * sigmoid(x_in[H:]) -> this lane's 16 channels of its row of the activation tile
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void flowstack_kernel(const FlowStackParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     fs4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (m == 0 || !last) v = *(const fs4*)(brs + 64 * m + c0 + 8 * q);
+                    if (m == 0 || !last) v = *(const fs4*)(rb + l * 2 * FS_H + 64 * m + c0 + 8 * q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[m][4 * q + e] = v[e];
                 }
@@ -428,7 +434,7 @@ hipError_t flowstack_launch(const FlowStackParams& p, hipStream_t stream) {
     const int halo = p.n_flows * p.layers, RC = W - 2 * halo;
     if (RC < 32 || p.Z != 2 * FS_HALF || p.z_in == p.z_out) return hipErrorInvalidValue;
     if (p.T4 <= 0 || p.B <= 0) return hipSuccess;
-    const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST + (size_t)W * FS_HALF) * sizeof(float);
+    const size_t lds = ((size_t)W * ZP + (size_t)(W + 2) * HP + (size_t)W * HP + FS_PRE + FS_POST + (size_t)W * FS_HALF + (size_t)p.layers * 4 * FS_H) * sizeof(float);
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;
