@@ -218,16 +218,26 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* qkv, float* 
     float m_run = -1e30f, l_run = 0.f;
     for (int j0 = 0; j0 < len; j0 += MHX_KT) {
         __syncthreads();
-        for (int idx = tid; idx < MHX_KT * (DK / 4); idx += 256) {   // K / V rows of this tile, zeros past the end
-            const int j = idx / (DK / 4), c4 = idx % (DK / 4);
-            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (j0 + j < len) {
-                const float* r = base + (long long)(j0 + j) * 3 * C + c4 * 4;
-                kv = *(const f32x4*)(r + C);
-                vv = *(const f32x4*)(r + 2 * C);
+        {   // K / V rows of this tile, zeros past the end: all six 16 B loads of a thread in flight, then the LDS writes
+            constexpr int NP = MHX_KT * (DK / 4) / 256;
+            static_assert(NP * 256 == MHX_KT * (DK / 4), "whole passes");
+            f32x4 kv[NP], vv[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * 256, j = idx / (DK / 4), c4 = idx % (DK / 4);
+                kv[u] = vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j0 + j < len) {
+                    const float* r = base + (long long)(j0 + j) * 3 * C + c4 * 4;
+                    kv[u] = *(const f32x4*)(r + C);
+                    vv[u] = *(const f32x4*)(r + 2 * C);
+                }
             }
-            *(f32x4*)(ks + j * MHX_PITCH + c4 * 16) = kv;
-            *(f32x4*)(vs + j * MHX_PITCH + c4 * 16) = vv;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * 256, j = idx / (DK / 4), c4 = idx % (DK / 4);
+                *(f32x4*)(ks + j * MHX_PITCH + c4 * 16) = kv[u];
+                *(f32x4*)(vs + j * MHX_PITCH + c4 * 16) = vv[u];
+            }
         }
         __syncthreads();
         // S^T[key][query] = sum_c K[key][c] Q[query][c]
@@ -342,16 +352,25 @@ __global__ __launch_bounds__(256) void mha_mfma_split_kernel(const float* qkv, f
     const char* vs = vs_all + wave * TILE;
     for (int j00 = 0; j00 < len; j00 += 4 * MHX_KT) {
         __syncthreads();
-        for (int idx = tid; idx < 4 * MHX_KT * (DK / 4); idx += 256) {   // K / V rows of this round (128 keys), zeros past the end
-            const int j = idx / (DK / 4), c4 = idx % (DK / 4);
-            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (j00 + j < len) {
-                const float* r = base + (long long)(j00 + j) * 3 * C + c4 * 4;
-                kv = *(const f32x4*)(r + C);
-                vv = *(const f32x4*)(r + 2 * C);
+        // K / V rows of this round (128 keys), zeros past the end: passes of 4 x 2 loads in flight per thread
+        for (int base_idx = tid; base_idx < 4 * MHX_KT * (DK / 4); base_idx += 4 * 256) {
+            f32x4 kv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base_idx + u * 256, j = idx / (DK / 4), c4 = idx % (DK / 4);
+                kv[u] = vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j00 + j < len) {
+                    const float* r = base + (long long)(j00 + j) * 3 * C + c4 * 4;
+                    kv[u] = *(const f32x4*)(r + C);
+                    vv[u] = *(const f32x4*)(r + 2 * C);
+                }
             }
-            *(f32x4*)(ks_all + j * MHX_PITCH + c4 * 16) = kv;
-            *(f32x4*)(vs_all + j * MHX_PITCH + c4 * 16) = vv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base_idx + u * 256, j = idx / (DK / 4), c4 = idx % (DK / 4);
+                *(f32x4*)(ks_all + j * MHX_PITCH + c4 * 16) = kv[u];
+                *(f32x4*)(vs_all + j * MHX_PITCH + c4 * 16) = vv[u];
+            }
         }
         __syncthreads();
         const int j0 = j00 + wave * MHX_KT;
