@@ -1,6 +1,23 @@
 // Shared device helpers of the fused HifiGAN kernels (rblock.hip, vpair.hip): bf16 conversion, the weight-fragment
 // ring preload and the static-offset MFMA contraction loop over an LDS activation tile.
 #pragma once
+// Cache policy of the fused vocoder kernels' global accesses (buffer-instruction aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// Their results are consumed by the NEXT launch, ~1 ms and ~1 GB of traffic later: streaming them (nt + sc1) keeps them from evicting
+// what the kernel re-reads — the x tile between staging and the epilogue's residual, the weight fragments.  Same-box A/B
+// (LABNOTES (yy)): stores 0 -> 18: -0.9 %; + the read-once operands (the stage sum, the epilogue's last read of x): -1.2 %; streaming
+// rblock's x loads as well: +2 % (worse: neighbouring tiles' halos re-read them).
+#ifndef VP_ST_AUX
+#define VP_ST_AUX 18   // y / activated-copy stores
+#endif
+#ifndef VP_LD_AUX
+#define VP_LD_AUX 18   // the stage sum read once by the accumulating ResBlocks
+#endif
+#ifndef VP_XI_AUX
+#define VP_XI_AUX 2    // vpair's epilogue: the last read of the x tile
+#endif
+#ifndef RB_X_AUX
+#define RB_X_AUX 0     // rblock's residual-stream loads: cached (halo rows are shared with the neighbouring tiles)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "voc_el.h"

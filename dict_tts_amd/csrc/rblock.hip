@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (!DTTS_DBG(p, 4)) v = __builtin_amdgcn_raw_buffer_load_b128(rs, o0 + (m * 32 * C + n * 32 + 8 * q) * 4, 0, 0);
+                if (!DTTS_DBG(p, 4)) v = __builtin_amdgcn_raw_buffer_load_b128(rs, o0 + (m * 32 * C + n * 32 + 8 * q) * 4, 0, RB_X_AUX);
                 const f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[n][4 * q + e] = f[e];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 ld[m][u] = u32x4{0u, 0u, 0u, 0u};
-                if (!DTTS_DBG(p, 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, g0 + (tile_row(m, u) - r0) * (C * 4), 0, 0);
+                if (!DTTS_DBG(p, 4)) ld[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, g0 + (tile_row(m, u) - r0) * (C * 4), 0, RB_X_AUX);
             }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             sold[m][u] = u32x4{0u, 0u, 0u, 0u};
-            if (p.mode >= 1) sold[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0);
+            if (p.mode >= 1) sold[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, VP_LD_AUX);
         }
     // fused conv_post: the stage output leaky_relu(xs / num_kernels) stays in LDS as an fp32 tile ([TT rows][C], rows outside
     // the utterance zero = conv_post's zero padding) instead of going to HBM; the transposition buffer moves behind it
@@ -340,11 +340,11 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
             if (!(p.mode == 2 && p.Sa && p.drop_S))   // the stage's consumers read only the bf16 copy: the fp32 sum can stay unwritten
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, VP_ST_AUX);
             if (p.mode == 2 && p.Sa) {
                 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
         }
     }

@@ -12,6 +12,10 @@
 //   * dual-output epilogue: fp32 residual stream + bf16 leaky_relu copy for the next convolution.
 // Same packed-weight format as conv1d.hip (context.hip:pack_conv), same contraction, same rounding points.
 #include "vconv.h"
+// the fp32 result rows are consumed by the next launch: non-temporal stores (rb_common.h: cache policy; -0.5 % same box)
+#ifndef VC_NT_STORE
+#define VC_NT_STORE 1
+#endif
 #include "rb_common.h"
 
 #ifndef VC_SB
@@ -375,7 +379,13 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 :
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]);
                     }
-                    if (p.yf) *(f32x4*)(p.yf + off[u] * p.ldyf + co) = o;
+                    if (p.yf) {
+#if VC_NT_STORE
+                        __builtin_nontemporal_store(o, (f32x4*)(p.yf + off[u] * p.ldyf + co));
+#else
+                        *(f32x4*)(p.yf + off[u] * p.ldyf + co) = o;
+#endif
+                    }
                     if (p.ya)
                         *(uint2*)(p.ya + off[u] * p.ldya + co) = make_uint2(pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)),
                                                                             pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope)));

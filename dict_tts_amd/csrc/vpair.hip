@@ -212,8 +212,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-            if (p.mode >= 2) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+            xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, VP_XI_AUX);
+            if (p.mode >= 2) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, VP_LD_AUX);
         }
     };
     fetch(0, xin[0], sold[0]);
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
             if (!(p.mode == 3 && p.ya && p.drop_y))   // the stage's consumers read only the bf16 copy
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, off, 0, VP_ST_AUX);
             if (p.mode == 3 && p.ya) {
                 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
         }
     }
