@@ -23,7 +23,8 @@ EXPORTS = ["dtts_default_config", "dtts_config_sizeof", "dtts_create", "dtts_des
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
            "dtts_load_weights", "dtts_text2mel_plan", "dtts_text2mel_forward", "dtts_text2mel_forward_ids",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
-           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset", "dtts_set_noise_seed", "dtts_vocoder_range_guard", "dtts_vocoder_clamped"]
+           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset", "dtts_set_noise_seed", "dtts_vocoder_range_guard", "dtts_vocoder_clamped",
+           "dtts_debug_check", "dtts_debug_poke"]
 
 
 class DttsConfig(C.Structure):
@@ -38,7 +39,7 @@ class DttsConfig(C.Structure):
         ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_dilation_sizes", (C.c_int32 * 3) * 4),
         ("vocoder_precision", C.c_int32), ("fft_layers", C.c_int32), ("fft_kernel_size", C.c_int32),
         ("fft_use_pos_embed", C.c_int32), ("fft_use_last_norm", C.c_int32), ("vocoder_unfused", C.c_int32), ("decoder_fp32", C.c_int32),
-        ("vocoder_range_guard", C.c_int32)]
+        ("vocoder_range_guard", C.c_int32), ("debug_redzone", C.c_int32), ("tune_flags", C.c_int32)]
 
 
 class DttsError(RuntimeError):
@@ -92,6 +93,8 @@ def load_library(path=None):
     lib.dtts_set_noise_seed.argtypes = [vp, C.c_uint64]
     lib.dtts_vocoder_range_guard.argtypes = [vp, i32]
     lib.dtts_vocoder_clamped.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
+    lib.dtts_debug_check.argtypes = [vp, C.POINTER(C.c_int64), vp]
+    lib.dtts_debug_poke.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -126,6 +129,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def last_error(self):
+        return self.lib.dtts_last_error(self.h).decode()
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -228,6 +234,17 @@ class Context:
 
     def vocoder_range_guard(self, enable):
         self._chk(self.lib.dtts_vocoder_range_guard(self.h, int(bool(enable))), "dtts_vocoder_range_guard")
+
+    def debug_check(self, stream):
+        """memory-safety mode (config.debug_redzone): red-zone bytes damaged so far (synchronises the stream); 0 = every kernel stayed
+        inside its buffers.  The first damaged zone is named by last_error()."""
+        n = C.c_int64(0)
+        self._chk(self.lib.dtts_debug_check(self.h, C.byref(n), stream), "dtts_debug_check")
+        return n.value
+
+    def debug_poke(self, stream):
+        """self-test of the memory-safety mode: damage one red-zone byte"""
+        self._chk(self.lib.dtts_debug_poke(self.h, stream), "dtts_debug_poke")
 
     def vocoder_clamped(self, stream, reset=True):
         """activations the fp16 ResBlock operands could not represent since the last reset (synchronises the stream)"""

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/dicttts_hip.h"
+#include "tune_env.h"
 #include "conv1d.h"
 #include "ops.h"
 #include "vconv.h"
@@ -38,30 +39,50 @@ struct HostTensor {
     }
 };
 
+// Memory-safety mode (dtts_config.debug_redzone, tests only): every workspace buffer sits between two RED ZONES of RZ bytes, the whole
+// arena is filled with 0xFF (= NaN as fp32 / fp16 / bf16, -1 as an integer) before each forward, so that
+//   * an out-of-range WRITE of a kernel damages a red zone (dtts_debug_check counts the bytes that are no longer 0xFF),
+//   * an out-of-range or stale READ that is actually consumed shows up as NaN in the outputs (buffers are never zero by luck).
+// Weight packs / tables (dev_alloc below) get the same red zones.  Off (the default): no red zones, no fills, no cost.
+constexpr size_t RZ = 4096;
+
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0;
-    hipError_t reserve(size_t n) {
+    bool debug = false;
+    struct Buf { size_t start, bytes; };
+    std::vector<Buf> bufs;   // debug: the buffers handed out since the last reserve / rewind
+    hipError_t reserve(size_t n, hipStream_t s) {
         off = 0;
-        if (n <= cap) return hipSuccess;
-        if (base) {
-            hipError_t e = hipDeviceSynchronize();
+        bufs.clear();
+        if (debug) n += 128 * (RZ + 256);
+        if (n > cap) {
+            if (base) {
+                hipError_t e = hipDeviceSynchronize();
+                if (e != hipSuccess) return e;
+                (void)hipFree(base);
+                base = nullptr;
+                cap = 0;
+            }
+            n = n + n / 8 + (1 << 20);
+            hipError_t e = hipMalloc((void**)&base, n);
             if (e != hipSuccess) return e;
-            (void)hipFree(base);
-            base = nullptr;
-            cap = 0;
+            cap = n;
         }
-        n = n + n / 8 + (1 << 20);
-        hipError_t e = hipMalloc((void**)&base, n);
-        if (e != hipSuccess) return e;
-        cap = n;
+        if (debug) return hipMemsetAsync(base, 0xFF, cap, s);
         return hipSuccess;
+    }
+    void rewind() {   // walk the same layout again (decode re-derives the buffers encode laid out)
+        off = 0;
+        bufs.clear();
     }
     template <class T>
     T* alloc(size_t count) {
+        if (debug) off += RZ;
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        if (off + bytes > cap) return nullptr;
+        if (off + bytes + (debug ? RZ : 0) > cap) return nullptr;
         T* p = (T*)(base + off);
+        if (debug) bufs.push_back({off, count * sizeof(T)});
         off += bytes;
         return p;
     }
@@ -69,6 +90,7 @@ struct Arena {
         if (base) (void)hipFree(base);
         base = nullptr;
         cap = off = 0;
+        bufs.clear();
     }
 };
 
@@ -106,6 +128,10 @@ struct dtts_ctx {
     std::string err;
     std::map<std::string, HostTensor> w;
     std::vector<void*> allocs;
+    bool debug_rz = false;                                   // dtts_config.debug_redzone
+    int device = 0;                                          // the HIP device that was current at dtts_create: weights and workspaces live there
+    struct StaticBuf { char* p; size_t bytes; };
+    std::vector<StaticBuf> rz_static;                         // debug: weight packs / tables (user pointer, payload bytes) between red zones
     bool acoustic_ready = false, vocoder_ready = false, fft_ready = false;
     // ---- FFT block stack
     struct FftLayer {
@@ -179,12 +205,41 @@ int fail(dtts_ctx* h, int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(h, DTTS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
     } while (0)
 
+// device allocation owned by the context (freed by dtts_destroy / dev_free); debug_redzone: between two 0xFF red zones
+void* dev_alloc(dtts_ctx* h, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 16);
+    char* d = nullptr;
+    if (!h->debug_rz) {
+        if (hipMalloc((void**)&d, bytes) != hipSuccess) return nullptr;
+        h->allocs.push_back(d);
+        return d;
+    }
+    const size_t padded = (bytes + 255) & ~(size_t)255;
+    if (hipMalloc((void**)&d, padded + 2 * RZ) != hipSuccess) return nullptr;
+    h->allocs.push_back(d);
+    if (hipMemset(d, 0xFF, padded + 2 * RZ) != hipSuccess) return nullptr;
+    h->rz_static.push_back({d + RZ, bytes});
+    return d + RZ;
+}
+void dev_free(dtts_ctx* h, void* user) {
+    if (!user) return;
+    char* basep = (char*)user - (h->debug_rz ? RZ : 0);
+    auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)basep);
+    if (it == h->allocs.end()) return;
+    (void)hipFree(basep);
+    h->allocs.erase(it);
+    for (size_t i = 0; i < h->rz_static.size(); ++i)
+        if (h->rz_static[i].p == (char*)user) {
+            h->rz_static.erase(h->rz_static.begin() + i);
+            break;
+        }
+}
+
 template <class T>
 T* upload(dtts_ctx* h, const std::vector<T>& v) {
-    T* d = nullptr;
-    if (hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
+    T* d = (T*)dev_alloc(h, v.size() * sizeof(T));
+    if (!d) return nullptr;
     if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    h->allocs.push_back(d);
     return d;
 }
 
@@ -632,9 +687,8 @@ int build_vocoder(dtts_ctx* h) {
     if (c.vocoder_precision == DTTS_VOC_F16 && c.audio_num_mel_bins % 4)
         return fail(h, DTTS_E_INVAL, "DTTS_VOC_F16 needs audio_num_mel_bins %% 4 == 0 (got %d); use DTTS_VOC_BF16X3", c.audio_num_mel_bins);
     if (!h->ovf_dev) {
-        if (hipMalloc((void**)&h->ovf_dev, sizeof(unsigned long long)) != hipSuccess || hipMemset(h->ovf_dev, 0, sizeof(unsigned long long)) != hipSuccess)
+        if (!(h->ovf_dev = (unsigned long long*)dev_alloc(h, sizeof(unsigned long long))) || hipMemset(h->ovf_dev, 0, sizeof(unsigned long long)) != hipSuccess)
             return fail(h, DTTS_E_NOMEM, "range-guard counter");
-        h->allocs.push_back(h->ovf_dev);
     }
     const int eng = c.vocoder_precision == DTTS_VOC_BF16 ? ENG_BF16 : ENG_BF16X3;                                   // serial convolutions
     const int eng_rb = c.vocoder_precision == DTTS_VOC_F16 ? ENG_F16 : eng;                                         // ResBlock convolutions
@@ -730,7 +784,7 @@ int build_vocoder(dtts_ctx* h) {
 // vconv parameter blocks (vocoder convolutions and the decoder's split-operand WaveNet layers)
 // -DDTTS_ABLATE builds: phase-ablation bits for the vocoder kernels, read ONCE when the library is loaded (never per launch)
 #ifdef DTTS_ABLATE
-static const int g_ablate = getenv("DTTS_VCONV_DBG") ? atoi(getenv("DTTS_VCONV_DBG")) : 0;
+static const int g_ablate = ablate_env("DTTS_VCONV_DBG") ? atoi(ablate_env("DTTS_VCONV_DBG")) : 0;
 #else
 constexpr int g_ablate = 0;
 #endif
@@ -974,7 +1028,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     }
     const int melC = h->conv_pre.C_in_pad;
     HIPCHK(h->a_voc.reserve(max_elems * (4 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
-                            (size_t)(nup + 2) * B * sizeof(int) + (64 << 10)));
+                            (size_t)(nup + 2) * B * sizeof(int) + (64 << 10), s));
     Arena& A = h->a_voc;
     float* Xf = A.alloc<float>(max_elems);
     float* Rf = A.alloc<float>(max_elems);
@@ -1129,7 +1183,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                     vp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
                     vp.dbg = g_ablate >> 8;
 #ifdef DTTS_ABLATE
-                    if (getenv("DTTS_VP_STATS")) {   // per-phase cycles of wave 0 (staging, c1, rewrite, c2, epilogue incl. store acks), printed per launch
+                    if (ablate_env("DTTS_VP_STATS")) {   // per-phase cycles of wave 0 (staging, c1, rewrite, c2, epilogue incl. store acks), printed per launch
                         static unsigned long long* dstats = nullptr;
                         if (!dstats) hipMalloc((void**)&dstats, 64);
                         hipMemsetAsync(dstats, 0, 64, s);
@@ -1279,9 +1333,10 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
         return fail(nullptr, DTTS_E_INVAL, "dtts_create: unsupported configuration");
     dtts_ctx* h = new dtts_ctx();
     h->cfg = *cfg;
-    // same-box A/B switches for tuning, read ONCE per context (never on the launch path): bit 0 = conv_post as its own kernel,
-    // bit 1 = upsamplers without the zero-tap skip, bit 3 = no whole-ResBlock fusion at C >= 128, bit 5 = 128-row tiles for the narrow split-operand upsamplers
-    h->tune = getenv("DTTS_TUNE") ? atoi(getenv("DTTS_TUNE")) : 0;
+    // A/B switches of tuning experiments: dtts_config.tune_flags (0 = the measured defaults; bits documented in include/dicttts_hip.h).
+    // The release library does NOT read the environment; -DDTTS_ABLATE builds (tools/ab_*.sh) OR the DTTS_TUNE variable in.
+    h->tune = cfg->tune_flags;
+    if (const char* e = ablate_env("DTTS_TUNE")) h->tune |= atoi(e);
     {   // prior-sample seed: different per context, process, device and start time (data-parallel ranks and restarts must not draw the
         // same z_p sequence); dtts_set_noise_seed makes it reproducible
         static unsigned long long instance = 0;
@@ -1294,6 +1349,9 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
         h->noise_seed = z ^ (z >> 31);
     }
     h->guard_on = cfg->vocoder_range_guard != 0;
+    (void)hipGetDevice(&h->device);
+    h->debug_rz = cfg->debug_redzone != 0;
+    h->a_fft.debug = h->a_enc.debug = h->a_dec.debug = h->a_voc.debug = h->debug_rz;
     *out = h;
     return DTTS_OK;
 }
@@ -1393,7 +1451,7 @@ int dtts_fft_blocks_forward(dtts_handle h, const float* x_in, const int32_t* len
     hipStream_t s = (hipStream_t)stream;
     const int C = c.hidden_size, F = 4 * C;
     const size_t rows = (size_t)B * T;
-    HIPCHK(h->a_fft.reserve(rows * (size_t)(C + C + 3 * C + C + F + 1) * sizeof(float) + (size_t)B * sizeof(int) + (64 << 10)));
+    HIPCHK(h->a_fft.reserve(rows * (size_t)(C + C + 3 * C + C + F + 1) * sizeof(float) + (size_t)B * sizeof(int) + (64 << 10), s));
     Arena& A = h->a_fft;
     float* x = A.alloc<float>(rows * C);
     float* hb = A.alloc<float>(rows * C);
@@ -1516,7 +1574,7 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
             max_elems = std::max<size_t>(max_elems, (size_t)B * (size_t)rows * (size_t)ch);
         }
     }
-    HIPCHK(h->a_voc.reserve(4 * (max_elems * sizeof(float) + 256) + (size_t)(nup + 2) * B * sizeof(int) + 8192));
+    HIPCHK(h->a_voc.reserve(4 * (max_elems * sizeof(float) + 256) + (size_t)(nup + 2) * B * sizeof(int) + 8192, s));
     float* bufX = h->a_voc.alloc<float>(max_elems);
     float* bufR = h->a_voc.alloc<float>(max_elems);
     float* bufT = h->a_voc.alloc<float>(max_elems);
@@ -1619,7 +1677,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     const size_t rows = (size_t)B * T_w;
     h->encoded = false;
     HIPCHK(h->a_enc.reserve(rows * (size_t)(12 * C + 3 * C + F + 2 * D + 3 * c.dur_chans + P + 8) * sizeof(float) +
-                            (size_t)B * L_k * T_w * sizeof(float) + (size_t)B * (T_w + 8) * 4 * sizeof(int) + (64 << 10)));
+                            (size_t)B * L_k * T_w * sizeof(float) + (size_t)B * (T_w + 8) * 4 * sizeof(int) + (64 << 10), s));
     Arena& A = h->a_enc;
     float* x = A.alloc<float>(rows * C);
     float* hb = A.alloc<float>(rows * C);
@@ -1761,7 +1819,7 @@ static int encode_impl(dtts_handle h, const int64_t* word_tokens, const float* k
     const int Hd = c.fvae_enc_dec_hidden, Hf = c.prior_glow_hidden;
     HIPCHK(h->a_dec.reserve(mrows * (size_t)(C + 1 + 2 + 2 * Hd * c.fvae_dec_n_layers + 3 * Hd + 8) * sizeof(float) +
                             qrows * (size_t)(C + 2 * c.latent_size + 2 * Hf * c.prior_glow_n_layers * (1 + c.prior_glow_n_blocks) + 3 * Hf + 16) * sizeof(float) +
-                            (size_t)B * T_w * 2 * Hd * c.fvae_dec_n_layers * sizeof(float) + (64 << 10)));
+                            (size_t)B * T_w * 2 * Hd * c.fvae_dec_n_layers * sizeof(float) + (64 << 10), s));
     h->m2w = h->a_dec.alloc<int64_t>(mrows);
     h->x_mask = h->a_dec.alloc<float>(mrows);
     if (!h->m2w || !h->x_mask) return fail(h, DTTS_E_NOMEM, "decoder workspace");
@@ -1809,61 +1867,99 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
             return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: entry %d has sense index %d; at most %d senses per word are supported",
                         e, std::max(pmmax[e], (int)km), DTTS_MAX_SENSES);
     }
-    if (h->t_entries) {   // a second upload replaces the table: release the previous one (nothing may still be using it)
-        HIPCHK(hipDeviceSynchronize());
-        void* old[] = {h->t_off, h->t_poff, h->t_pmmax, h->t_keys, h->t_values, h->t_key_map, h->t_pinyin, h->t_pinyin_map};
-        for (void* q : old) {
-            auto it = std::find(h->allocs.begin(), h->allocs.end(), q);
-            if (it == h->allocs.end()) continue;   // t_values aliases t_keys when the table was uploaded without values
-            (void)hipFree(q);
-            h->allocs.erase(it);
-        }
-        h->t_entries = 0;
-    }
+    // ---- build the NEW table completely before touching the one in use: a failed re-upload leaves the previous table working
+    int dev_cur = -1;
+    (void)hipGetDevice(&dev_cur);
+    if (dev_cur != h->device)
+        return fail(h, DTTS_E_STATE, "dtts_dict_table_upload: the current HIP device is %d, the context was created on device %d", dev_cur, h->device);
+    std::vector<void*> fresh;   // the new table's allocations (released again if anything below fails)
+    const char* what = nullptr;
+    hipError_t herr = hipSuccess;
     auto up = [&](const void* src, size_t bytes) -> void* {
-        void* d = nullptr;
-        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
-        h->allocs.push_back(d);   // owned by the context from here on, also when the copy below fails
-        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        void* d = dev_alloc(h, bytes);
+        if (!d) {
+            what = "device allocation";
+            return nullptr;
+        }
+        fresh.push_back(d);
+        if (bytes && (herr = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+            what = "host-to-device copy";
+            return nullptr;
+        }
         return d;
     };
-    h->t_off = (int*)up(tok_off, sizeof(int) * (n_entries + 1));
-    h->t_poff = (int*)up(pin_off, sizeof(int) * (n_entries + 1));
-    h->t_pmmax = (int*)up(pmmax.data(), sizeof(int) * n_entries);
     // SURVEY 8d "resident-table path": the table holds the PROJECTED rows K = k_transform(key), V = v_transform(value)
     // (dict_encoder.py:36-39: the reference projects every gloss row of every batch; here once, at upload) — 2 x hidden_size floats per
-    // row instead of 768 (+ 768), and the logit becomes k . q in the reference's own association order.  DTTS_TUNE bit 64 keeps the raw
+    // row instead of 768 (+ 768), and the logit becomes k . q in the reference's own association order.  tune bit 64 keeps the raw
     // rows (round 2's table: the re-associated kernel of the tensor API reads them).
-    h->t_projected = !(h->tune & 64);
-    if (h->t_projected) {
-        if (!h->acoustic_ready) return fail(h, DTTS_E_STATE, "dtts_dict_table_upload: the acoustic weights must be finalized first (the table stores k_transform / v_transform projections)");
+    const bool projected = !(h->tune & 64);
+    if (projected && !h->acoustic_ready)
+        return fail(h, DTTS_E_STATE, "dtts_dict_table_upload: the acoustic weights must be finalized first (the table stores k_transform / v_transform projections)");
+    if (projected && nL > (size_t)INT_MAX / 2) return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: %zu gloss rows", nL);
+    int* n_off = (int*)up(tok_off, sizeof(int) * (n_entries + 1));
+    int* n_poff = (int*)up(pin_off, sizeof(int) * (n_entries + 1));
+    int* n_pmmax = (int*)up(pmmax.data(), sizeof(int) * n_entries);
+    float *n_keys = nullptr, *n_values = nullptr;
+    if (projected) {
         const int C = h->cfg.hidden_size;
-        if (nL > (size_t)INT_MAX / 2) return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: %zu gloss rows", nL);
         float* raw = nullptr;
+        hipStream_t ps = nullptr;   // the projection runs on its own stream, on the device that is current now (= the context's: its weights live there)
+        if (!what && (herr = hipMalloc((void**)&raw, std::max<size_t>(nL * D * sizeof(float), 16))) != hipSuccess) what = "staging buffer allocation";
+        if (!what && (herr = hipStreamCreate(&ps)) != hipSuccess) what = "hipStreamCreate";
         auto proj = [&](const float* src, const PackedConv& L) -> float* {   // [nL][D] host rows -> [nL][C] device rows
-            float* out = nullptr;
-            if (hipMalloc((void**)&out, std::max<size_t>(nL * C * sizeof(float), 16)) != hipSuccess) return nullptr;
-            h->allocs.push_back(out);
+            if (what) return nullptr;
+            float* out = (float*)dev_alloc(h, nL * C * sizeof(float));
+            if (!out) {
+                what = "device allocation";
+                return nullptr;
+            }
+            fresh.push_back(out);
             if (nL == 0) return out;
-            if (hipMemcpy(raw, src, nL * D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+            if ((herr = hipMemcpyAsync(raw, src, nL * D * sizeof(float), hipMemcpyHostToDevice, ps)) != hipSuccess) {
+                what = "host-to-device copy";
+                return nullptr;
+            }
             ConvParams p = base_params(raw, D, 1, (int)nL, (int)nL, out, C);
-            if (conv1d_launch(L, p, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+            if ((herr = conv1d_launch(L, p, ps)) != hipSuccess) {
+                what = "projection kernel launch";
+                return nullptr;
+            }
+            if ((herr = hipStreamSynchronize(ps)) != hipSuccess) {
+                what = "projection kernel";
+                return nullptr;
+            }
             return out;
         };
-        if (hipMalloc((void**)&raw, std::max<size_t>(nL * D * sizeof(float), 16)) != hipSuccess)
-            return fail(h, DTTS_E_NOMEM, "dtts_dict_table_upload: staging buffer for %zu gloss rows", nL);
-        h->t_keys = proj(keys, h->s2_k);
-        h->t_values = proj(values ? values : keys, h->s2_v);
-        (void)hipFree(raw);
+        n_keys = proj(keys, h->s2_k);
+        n_values = proj(values ? values : keys, h->s2_v);
+        if (ps) (void)hipStreamDestroy(ps);
+        if (raw) (void)hipFree(raw);
     } else {
-        h->t_keys = (float*)up(keys, nL * D * sizeof(float));
-        h->t_values = values ? (float*)up(values, nL * D * sizeof(float)) : h->t_keys;  // the reference stores key == value
+        n_keys = (float*)up(keys, nL * D * sizeof(float));
+        n_values = values ? (float*)up(values, nL * D * sizeof(float)) : n_keys;  // the reference stores key == value
     }
-    h->t_key_map = (float*)up(key_map, nL * sizeof(float));
-    h->t_pinyin = (int64_t*)up(pinyin, nP * sizeof(int64_t));
-    h->t_pinyin_map = (int64_t*)up(pinyin_map, nP * sizeof(int64_t));
-    if (!h->t_off || !h->t_poff || !h->t_pmmax || !h->t_keys || !h->t_values || !h->t_key_map || !h->t_pinyin || !h->t_pinyin_map)
-        return fail(h, DTTS_E_NOMEM, "dtts_dict_table_upload: device allocation / copy failed");
+    float* n_key_map = (float*)up(key_map, nL * sizeof(float));
+    int64_t* n_pinyin = (int64_t*)up(pinyin, nP * sizeof(int64_t));
+    int64_t* n_pinyin_map = (int64_t*)up(pinyin_map, nP * sizeof(int64_t));
+    if (what || !n_off || !n_poff || !n_pmmax || !n_keys || !n_values || !n_key_map || !n_pinyin || !n_pinyin_map) {
+        for (void* q : fresh) dev_free(h, q);
+        return fail(h, what && strstr(what, "allocation") ? DTTS_E_NOMEM : DTTS_E_HIP, "dtts_dict_table_upload: %s failed (%s)%s",
+                    what ? what : "device allocation", hipGetErrorString(herr), h->t_entries ? "; the previous table stays in use" : "");
+    }
+    if (h->t_entries) {   // a second upload replaces the table: release the previous one (nothing may still be using it)
+        HIPCHK(hipDeviceSynchronize());
+        void* old[] = {h->t_off, h->t_poff, h->t_pmmax, h->t_keys, h->t_values != h->t_keys ? h->t_values : nullptr, h->t_key_map, h->t_pinyin, h->t_pinyin_map};
+        for (void* q : old) dev_free(h, q);
+    }
+    h->t_off = n_off;
+    h->t_poff = n_poff;
+    h->t_pmmax = n_pmmax;
+    h->t_keys = n_keys;
+    h->t_values = n_values;
+    h->t_key_map = n_key_map;
+    h->t_pinyin = n_pinyin;
+    h->t_pinyin_map = n_pinyin_map;
+    h->t_projected = projected;
     h->t_entries = n_entries;
     return DTTS_OK;
 }
@@ -1882,7 +1978,7 @@ static int decode_impl(dtts_handle h, const float* z_p, int z_ld, float* mel_out
     Timed t_fvae(h, DTTS_TIMER_STAGE_FVAE, s);   // 'fvae' (model.py:57) + the gather-expand of run_text_encoder
     Arena& A = h->a_dec;
     // (m2w and x_mask were allocated first by encode; everything below is re-allocated after them on every call)
-    A.off = 0;
+    A.rewind();
     (void)A.alloc<int64_t>(mrows);
     (void)A.alloc<float>(mrows);
     float* g = A.alloc<float>(mrows * C);
@@ -2151,6 +2247,87 @@ int dtts_timer_reset(dtts_handle h) {
         t.ms_done = 0;
         t.launches = 0;
     }
+    return DTTS_OK;
+}
+
+// ---- memory-safety mode (dtts_config.debug_redzone): verify every red zone of the workspaces and the weight packs
+namespace {
+struct RzZone { const unsigned char* p; unsigned n; unsigned id; };
+__global__ void redzone_check_kernel(const RzZone* z, int nz, unsigned long long* out) {   // out[0] = damaged bytes, out[1] = lowest damaged zone id
+    const RzZone q = z[blockIdx.x];
+    unsigned bad = 0;
+    for (unsigned i = threadIdx.x; i < q.n; i += blockDim.x) bad += q.p[i] != 0xFF ? 1u : 0u;
+    if (bad) {
+        atomicAdd(out, (unsigned long long)bad);
+        atomicMin(out + 1, (unsigned long long)q.id);
+    }
+}
+} // namespace
+
+// harness self-test: damage ONE red-zone byte (the first byte after the first buffer of the first workspace in use, or after the first
+// weight pack) the way an off-by-one store of a kernel would, so that a test can show dtts_debug_check notices
+int dtts_debug_poke(dtts_handle h, dtts_stream stream) {
+    if (!h) return DTTS_E_INVAL;
+    if (!h->debug_rz) return fail(h, DTTS_E_STATE, "dtts_debug_poke: the context was not created with dtts_config.debug_redzone = 1");
+    char* target = nullptr;
+    for (Arena* a : {&h->a_voc, &h->a_enc, &h->a_dec, &h->a_fft})
+        if (!target && a->base && !a->bufs.empty()) target = a->base + a->bufs[0].start + a->bufs[0].bytes;
+    if (!target && !h->rz_static.empty()) target = h->rz_static[0].p + h->rz_static[0].bytes;
+    if (!target) return fail(h, DTTS_E_STATE, "dtts_debug_poke: nothing allocated yet");
+    HIPCHK(hipMemsetAsync(target, 0, 1, (hipStream_t)stream));
+    return DTTS_OK;
+}
+
+int dtts_debug_check(dtts_handle h, int64_t* damaged_bytes, dtts_stream stream) {
+    if (!h || !damaged_bytes) return DTTS_E_INVAL;
+    *damaged_bytes = -1;
+    if (!h->debug_rz) return fail(h, DTTS_E_STATE, "dtts_debug_check: the context was not created with dtts_config.debug_redzone = 1");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<RzZone> zones;
+    std::vector<std::string> names;
+    auto add = [&](const char* base, size_t start, size_t bytes, size_t limit, const std::string& name) {   // the zones before and after one buffer
+        zones.push_back({(const unsigned char*)base + start - RZ, (unsigned)RZ, (unsigned)names.size()});
+        names.push_back(name + ": zone BEFORE the buffer");
+        const size_t tail = std::min(RZ, limit - (start + bytes));
+        zones.push_back({(const unsigned char*)base + start + bytes, (unsigned)tail, (unsigned)names.size()});
+        names.push_back(name + ": zone AFTER the buffer");
+    };
+    const std::pair<const char*, Arena*> arenas[] = {{"encode workspace", &h->a_enc}, {"decode workspace", &h->a_dec}, {"vocoder workspace", &h->a_voc}, {"fft workspace", &h->a_fft}};
+    for (const auto& a : arenas)
+        for (size_t i = 0; i < a.second->bufs.size(); ++i) {
+            const auto& b = a.second->bufs[i];
+            const size_t limit = i + 1 < a.second->bufs.size() ? a.second->bufs[i + 1].start - RZ + RZ : a.second->cap;   // (the next buffer's own front zone follows)
+            add(a.second->base, b.start, b.bytes, std::min(limit, a.second->cap), std::string(a.first) + " buffer #" + std::to_string(i) + " (" + std::to_string(b.bytes) + " B)");
+        }
+    for (size_t i = 0; i < h->rz_static.size(); ++i) {
+        const auto& b = h->rz_static[i];
+        const size_t padded = (b.bytes + 255) & ~(size_t)255;
+        add(b.p, 0, b.bytes, padded + RZ, "weight pack / table #" + std::to_string(i) + " (" + std::to_string(b.bytes) + " B)");
+    }
+    if (zones.empty()) {
+        *damaged_bytes = 0;
+        return DTTS_OK;
+    }
+    RzZone* dz = nullptr;
+    unsigned long long* dout = nullptr;
+    unsigned long long hout[2] = {0ull, ~0ull};
+    HIPCHK(hipMalloc((void**)&dz, zones.size() * sizeof(RzZone)));
+    hipError_t e = hipMalloc((void**)&dout, sizeof hout);
+    if (e == hipSuccess) e = hipMemcpy(dz, zones.data(), zones.size() * sizeof(RzZone), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dout, hout, sizeof hout, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(redzone_check_kernel, dim3((unsigned)zones.size()), dim3(256), 0, s, dz, (int)zones.size(), dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(hout, dout, sizeof hout, hipMemcpyDeviceToHost);
+    (void)hipFree(dz);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(h, DTTS_E_HIP, "dtts_debug_check: %s", hipGetErrorString(e));
+    *damaged_bytes = (int64_t)hout[0];
+    if (hout[0]) h->err = "red zone damaged: " + std::to_string(hout[0]) + " bytes in " + std::to_string(zones.size()) + " zones; first: " +
+                          (hout[1] < names.size() ? names[hout[1]] : std::string("?"));
     return DTTS_OK;
 }
 

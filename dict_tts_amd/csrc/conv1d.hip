@@ -10,6 +10,7 @@
 // For fp32 each lane reads 4 consecutive channels (one ds_read_b128) and spends them on 4 successive
 // 32x32x2 MFMAs; the weight packing uses the same k permutation, so the contraction is unchanged.
 #include "conv1d.h"
+#include "tune_env.h"
 #include <type_traits>
 #include <cstdlib>
 
@@ -672,7 +673,7 @@ static bool launch_short_policy(const ConvParams& p, hipStream_t stream, hipErro
     }
     // split the contraction over the workgroup's waves (each output tile's chain 2x / 4x shorter, 2x / 4x the workgroups) as far
     // as ALL workgroups stay co-resident: a second round of workgroups costs more than the shorter chains give
-    static const int ks_env = [] { const char* e = getenv("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
+    static const int ks_env = [] { const char* e = ablate_env("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
     const int n_cu = cu_count();
     const int NG = p.C_in_pad / KG;
     const size_t per_cu_lds = (160 * 1024) / lds;

@@ -1,5 +1,6 @@
 // Non-GEMM kernels of the Dict-TTS path.  See ops.h for the contracts and the reference lines they follow.
 #include "ops.h"
+#include "tune_env.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -483,7 +484,7 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
     const int dk = C / heads;
     if (dk == MHX_DK) {
         // few long sequences: keys split over the waves (see mha_mfma_split_kernel) while the 128-query form would fill < half the CUs
-        static const bool split_ok = [] { const char* e = getenv("DTTS_MHA_SPLIT"); return !e || atoi(e) != 0; }();
+        static const bool split_ok = [] { const char* e = ablate_env("DTTS_MHA_SPLIT"); return !e || atoi(e) != 0; }();
         if (split_ok && T > 128 && (long long)((T + 127) / 128) * heads * B <= 128) {
             constexpr int LDS = 8 * MHX_KT * MHX_PITCH + 8 * 32 * (int)sizeof(float);
             static bool configured_dev[64] = {};

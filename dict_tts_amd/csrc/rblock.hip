@@ -13,6 +13,7 @@
 // PS = 1 (all but C = 32): persistent workgroups walk the batch's valid tiles, the next tile's x is fetched straight into the
 // residual registers (accumulator layout, no LDS transposition) slab by slab as the epilogue releases them.
 #include "rblock.h"
+#include "tune_env.h"
 #include "rb_common.h"
 
 #include <algorithm>
@@ -48,12 +49,15 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // computed the NEXT tile's residual stream is already on its way into registers, so the exposed HBM round trip and the
     // LDS transposition of a per-tile x load disappear from every tile but the workgroup's first.
     int* pre = (int*)(smem + p.pre_off);
-    // zero the guard bands once
-    for (int idx = tid; idx < 2 * RB_GUARD * (PITCH / 16); idx += THREADS) {
-        const int r = idx / (PITCH / 16), c = idx % (PITCH / 16);
-        const int row = r < RB_GUARD ? r : W + r;
-        *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
-    }
+    // zero the guard bands (once; the fused conv_post's fp32 output tile aliases them: again after every tile there)
+    auto zero_guard_bands = [&](int t) {
+        for (int idx = t; idx < 2 * RB_GUARD * (PITCH / 16); idx += THREADS) {
+            const int r = idx / (PITCH / 16), c = idx % (PITCH / 16);
+            const int row = r < RB_GUARD ? r : W + r;
+            *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+    };
+    zero_guard_bands(tid);
     int total = 0, j = blockIdx.x;
     if constexpr (PS) {
         for (int i = tid; i < p.B; i += THREADS) {
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             const int row = (wt * MT + m) * 32 + (lane & 31);
             const int t = base_t + row;
             const bool inb = all_inb || (t >= 0 && t < len);
+            // range guard: only the rows this tile OUTPUTS are counted.  Every in-utterance row is an output row of exactly one tile
+            // and carries the exact activation there at each of the six stages, so the count is a census; halo rows (recomputed,
+            // increasingly inexact towards the tile edge, their results discarded) are another tile's output rows.
+            const bool counted = inb && row >= H && row < H + TT;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
                     const f32x4 v4 = {v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]};
                     uint2 pk = act4<EL>(v4, 0.1f);
-                    if constexpr (GUARD) n_ovf += inb ? ovf4(v4, 0.1f) : 0;
+                    if constexpr (GUARD) n_ovf += counted ? ovf4(v4, 0.1f) : 0;
                     if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
@@ -377,10 +385,17 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }
     }   // (epilogue)
     if constexpr (GUARD) {
-        if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);   // (halo rows are counted by every tile that recomputes them: a count, not a census)
+        if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);
     }
     if (!has_next) break;
-    if (p.wav) __syncthreads();   // the output tile aliases the activation buffer the next tile is about to write
+    if (p.wav) {
+        // the fp32 output tile aliases the activation buffer AND its guard bands: conv_post's reads are over behind this barrier, then
+        // the bands are zero again before the next tile's first convolution reads them (the barrier after its first write_act orders
+        // both).  Without it a workgroup's 2nd+ tile ran its outermost halo rows on fp32 bit patterns read as 16-bit operands: the
+        // results of those rows are discarded (H covers the six receptive fields), but the range guard counted their Inf / huge values.
+        __syncthreads();
+        zero_guard_bands(threadIdx.x);
+    }
     j = jn;
     b = bn;
     len = lenn;
@@ -460,10 +475,10 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
     // C = 32: k >= 7 on 1024-row tiles (8 waves over time, one persistent workgroup per CU: the 6 (k - 1)-row halo costs 12 % of a
     // k = 11 tile instead of 23 %; -8 % on that launch), k = 3 on 512-row tiles, two 4-wave workgroups per CU, one tile each (the
     // 1024-row form is 14 % slower there).  DTTS_RB32=0: 512-row tiles for every k (round 2).
-    static const int rb32 = getenv("DTTS_RB32") ? atoi(getenv("DTTS_RB32")) : 1;
+    static const int rb32 = ablate_env("DTTS_RB32") ? atoi(ablate_env("DTTS_RB32")) : 1;
     // small batches (B = 1: one sentence): when the default tiles leave more than half of the CUs without one, the launch takes as long
     // as ONE tile -> half-size tiles (more halo recomputed, but twice the CUs at work)
-    static const bool small_ok = [] { const char* e = getenv("DTTS_RB_SMALL"); return !e || atoi(e) != 0; }();
+    static const bool small_ok = [] { const char* e = ablate_env("DTTS_RB_SMALL"); return !e || atoi(e) != 0; }();
     static int cus_dev[64] = {};
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);

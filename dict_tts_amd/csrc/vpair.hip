@@ -9,6 +9,7 @@
 //     epilogue and writes only the fp32 result (or accumulates into the stage sum xs for the last iteration).
 // HBM bytes per row and iteration: ~0.8 KB in + 0.5 KB out.  4 waves over output channels, 3 workgroups per CU.
 #include "vpair.h"
+#include "tune_env.h"
 
 #include "rb_common.h"
 
@@ -119,7 +120,10 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             for (int u = 0; u < U; ++u) {
                 if (kb + u >= nk) continue;
                 const f32x4 f = __builtin_bit_cast(f32x4, v[u]);
-                if constexpr (GUARD) n_ovf += ovf4(f, 0.1f);   // (rows outside the utterance arrive as zeros)
+                if constexpr (GUARD) {   // census: only the rows this tile outputs (rows outside the utterance arrive as zeros)
+                    const int rr = r0 + (kb + u) * RSTEP - h1 - h2;
+                    n_ovf += (rr >= 0 && rr < TTe) ? ovf4(f, 0.1f) : 0;
+                }
                 *(uint2*)(lrow + (kb + u) * (RSTEP * PITCH)) = act4<EL>(f, 0.1f);
             }
         }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v4 = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
                 uint2 pk = act4<EL>(v4, 0.1f);
-                if constexpr (GUARD) n_ovf += inb ? ovf4(v4, 0.1f) : 0;
+                if constexpr (GUARD) n_ovf += (inb && r >= h2 && r < h2 + TTe) ? ovf4(v4, 0.1f) : 0;
                 if (!inb) pk = make_uint2(0, 0);
                 *(uint2*)(smem + r * PITCH + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 2) = pk;
             }
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
     if constexpr (GUARD) {
-        if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);   // (halo rows are counted by every tile that stages them: a count, not a census)
+        if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);   // (output rows only: every in-utterance row exactly once per launch)
     }
     if (DTTS_DBG(p, 2)) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
@@ -343,7 +347,7 @@ template <int EL>
 static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t stream) {
     // small batches (B = 1: one sentence): the default tiles would leave most CUs without one and the launch takes as long as ONE tile
     // -> half-size tiles (more halo rows recomputed, twice the weight stream per row, but twice the CUs at work)
-    static const bool small_ok = [] { const char* e = getenv("DTTS_VP_SMALL"); return !e || atoi(e) != 0; }();
+    static const bool small_ok = [] { const char* e = ablate_env("DTTS_VP_SMALL"); return !e || atoi(e) != 0; }();
     auto tiles_of = [&](int tt) { return (long long)p.B * ((p.T + (tt - (p.K - 1)) - 1) / (tt - (p.K - 1))); };
     if (C == 256) {
         if (small_ok && 2 * tiles_of(128) <= vpair_cus()) return vpair_launch_tt<256, 64, EL>(p, stream);

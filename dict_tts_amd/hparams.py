@@ -137,4 +137,8 @@ def fill_abi_config(cfg, hp=None, voc=None, n_phone=None, vocoder_precision=None
                 cfg.resblock_dilation_sizes[i][j] = int(rd[i][j])
     if vocoder_precision is not None:
         cfg.vocoder_precision = int(vocoder_precision)
+    # A/B switches of tuning experiments (include/dicttts_hip.h: dtts_config.tune_flags; 0 = the measured defaults).  An explicit
+    # key of the hparams / vocoder config, never the process environment.
+    cfg.tune_flags = int((hp or {}).get("dtts_tune_flags", 0)) | int((voc or {}).get("dtts_tune_flags", 0))
+    cfg.debug_redzone = 1 if ((hp or {}).get("dtts_debug_redzone") or (voc or {}).get("dtts_debug_redzone")) else 0
     return cfg

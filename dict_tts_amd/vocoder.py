@@ -61,14 +61,16 @@ def find_vocoder_checkpoint(base_dir):
 class HifiGAN:
     """Same contract as the reference class: ``spec2wav(mel[T,80], **ignored) -> np.float32[T*hop]``."""
 
-    GUARD_CALLS = 4   # precision not chosen explicitly: the first calls run with the fp16 range guard on
+    GUARD_CALLS = 4    # precision not chosen explicitly: the first calls run with the fp16 range guard on ...
+    GUARD_EVERY = 16   # ... and afterwards every GUARD_EVERY-th call does (overflow depends on the input, not only on the checkpoint)
 
     def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False, range_guard=None):
         """precision: None (= env DTTS_VOCODER_PRECISION, else AUTO) | 'f16' | 'bf16' | 'bf16x3' | abi.VOC_*.
         AUTO = DTTS_VOC_F16 (the waveform-exact default) with two safety nets, because fp16 operands have a narrower range than
         the reference's fp32 arithmetic: (1) a generator shape the fused fp16 kernels do not cover falls back to DTTS_VOC_BF16X3
-        at construction; (2) the first GUARD_CALLS forward calls run with the library's range guard on (dtts_vocoder_range_guard)
-        and a call that saturated / overflowed an fp16 activation is REDONE in DTTS_VOC_BF16X3, which the object then keeps.
+        at construction; (2) the first GUARD_CALLS forward calls, and every GUARD_EVERY-th call after them, run with the library's
+        range guard on (dtts_vocoder_range_guard; a guarded call synchronises its stream to read the count) and a call that
+        saturated / overflowed an fp16 activation is REDONE in DTTS_VOC_BF16X3, which the object then keeps.
         An explicit precision is taken literally; range_guard=True then keeps the guard on for every call and raises on a clamp."""
         if state_dict is None:
             config, state_dict = find_vocoder_checkpoint(hparams_mod.hparams["vocoder_ckpt"])   # looked up at call time: the
@@ -85,8 +87,10 @@ class HifiGAN:
         elif isinstance(precision, str):
             precision = abi.VOC_PRECISIONS[precision]
         self._unfused = unfused
-        self._guard_left = 0
+        self._guard_left = 0      # -1: every call guarded (range_guard=True); > 0: the initial guarded calls left; 0 + _auto_guard: sampled
         self._guard_raise = False
+        self._auto_guard = False
+        self._calls = 0
         self._state_dict = None
         if ctx is not None:
             self.precision = precision
@@ -107,7 +111,8 @@ class HifiGAN:
             if guard:
                 self._guard_left = -1 if range_guard else self.GUARD_CALLS
                 self._guard_raise = bool(range_guard) and not auto
-                self._state_dict = state_dict if auto else None   # kept until the guarded calls are over (needed for the fallback)
+                self._auto_guard = auto
+                self._state_dict = state_dict if auto else None   # kept for the fallback (host tensors the caller handed over)
         self.hop = self.ctx.hop()
 
     def _build(self, state_dict, precision, guard):
@@ -135,8 +140,14 @@ class HifiGAN:
         if lens is not None:
             lens = lens.to(device=mel.device, dtype=torch.int32).contiguous()
         stream = torch.cuda.current_stream().cuda_stream
+        sampled = False
+        if self._auto_guard and self._guard_left == 0:   # past the initial guarded calls: every GUARD_EVERY-th call is guarded again
+            self._calls += 1
+            sampled = self._calls % self.GUARD_EVERY == 0
+            if sampled:
+                self.ctx.vocoder_range_guard(True)
         self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
-        if self._guard_left:
+        if self._guard_left or sampled:
             n = self.ctx.vocoder_clamped(stream)   # (synchronises the stream: only during the guarded calls)
             if n:
                 if self._guard_raise or self._state_dict is None:
@@ -145,14 +156,16 @@ class HifiGAN:
                 import warnings
                 warnings.warn(f"HifiGAN: {n} activations exceeded the fp16 range; switching to DTTS_VOC_BF16X3 and redoing this call")
                 self._guard_left = 0
+                self._auto_guard = False
                 self._build(self._state_dict, abi.VOC_BF16X3, False)
                 self._state_dict = None
                 self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
+            elif sampled:
+                self.ctx.vocoder_range_guard(False)
             elif self._guard_left > 0:
                 self._guard_left -= 1
                 if self._guard_left == 0:
                     self.ctx.vocoder_range_guard(False)
-                    self._state_dict = None
         return wav
 
     def to_int16(self, wav, lens=None, norm=False):

@@ -96,6 +96,17 @@ typedef struct dtts_config {
     int32_t vocoder_unfused;          /* testing aid, DTTS_VOC_BF16 only: 1 = one kernel per convolution instead of the fused ResBlock kernels */
     int32_t decoder_fp32;             /* 1 = FVAE decoder WaveNet on exact fp32 MFMA (round 1); 0 (default) = bf16 hi/lo split operands */
     int32_t vocoder_range_guard;      /* DTTS_VOC_F16: 1 = start with the fp16 range guard on (dtts_vocoder_range_guard) */
+    int32_t debug_redzone;            /* testing aid: 1 = memory-safety mode — every workspace buffer and weight pack sits between 4 KiB red
+                                         zones, workspaces are filled with 0xFF (NaN) before each forward; dtts_debug_check verifies the zones */
+    int32_t tune_flags;               /* A/B switches of tuning experiments (tools/ab_*.sh); 0 = the measured defaults.  The library never
+                                         reads the process environment: arithmetic and layout follow this struct alone.  Bits that change
+                                         ARITHMETIC: 8 prior flow launch by launch on exact-fp32 kernels, 10 fp32 g_pre_net, 11 fp32 flow conditioning,
+                                         13 two-product fp16 ups.1 (eats waveform margin), 16 strided g_pre_net, 17 fp32 MFMA instead of the
+                                         three-piece bf16 products; LAYOUT: 6 raw (unprojected) dictionary table; SCHEDULE only: 0 conv_post as its
+                                         own kernel, 1 upsamplers without the zero-tap skip, 2 static tile assignment, 3 no whole-ResBlock fusion
+                                         at C >= 128, 4 per-launch timer events, 5 128-row tiles for the narrow upsamplers.  (Builds made with
+                                         -DDTTS_ABLATE — `make ablate`, tools/ab_*.sh — additionally OR the DTTS_TUNE environment variable in and
+                                         honour a few more schedule-only variables; the release library has no such code.) */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
@@ -264,6 +275,15 @@ int dtts_set_noise_seed(dtts_handle h, uint64_t seed);
  * input at hand: use DTTS_VOC_BF16X3 (dict_tts_amd/vocoder.py does that automatically when the precision was not chosen explicitly). */
 int dtts_vocoder_range_guard(dtts_handle h, int enable);
 int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream stream);
+
+/* Memory-safety mode (dtts_config.debug_redzone = 1; a testing aid with no counterpart in the reference — the kernels behind this ABI
+ * address raw HBM).  Every workspace buffer of the last encode / decode / vocoder / FFT-block call and every weight pack / table sits
+ * between two 4 KiB red zones filled with 0xFF, and the workspaces are filled with 0xFF (NaN) before each forward.  dtts_debug_check
+ * synchronises `stream` and counts the red-zone bytes that are no longer 0xFF (= an out-of-range WRITE; dtts_last_error names the first
+ * damaged zone); an out-of-range or stale READ that is consumed shows up as NaN in the outputs.  DTTS_E_STATE without the mode. */
+int dtts_debug_check(dtts_handle h, int64_t* damaged_bytes, dtts_stream stream);
+/* self-test of the mode: damages one red-zone byte (as an off-by-one store would); the next dtts_debug_check must report it */
+int dtts_debug_poke(dtts_handle h, dtts_stream stream);
 
 /*
  * Instrumentation used by bench.py: accumulated device time (hipEvent pairs recorded on the caller's stream

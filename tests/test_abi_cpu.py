@@ -37,7 +37,7 @@ def test_default_config_matches_reference_hparams(lib):
     assert list(cfg.upsample_rates)[:4] == [8, 8, 2, 2] and list(cfg.upsample_kernel_sizes)[:4] == [16, 16, 4, 4]
     assert [list(r) for r in cfg.resblock_dilation_sizes][:3] == [[1, 3, 5]] * 3
     # struct layout: ctypes mirror and the C struct agree on the size
-    assert abi.C.sizeof(abi.DttsConfig) == lib.dtts_config_sizeof() == 4 * (25 + 8 + 8 + 1 + 4 + 12 + 1 + 4 + 3)
+    assert abi.C.sizeof(abi.DttsConfig) == lib.dtts_config_sizeof() == 4 * (25 + 8 + 8 + 1 + 4 + 12 + 1 + 4 + 5)
     assert cfg.vocoder_precision == abi.VOC_F16 and cfg.vocoder_unfused == 0   # the waveform-exact mode is the default
     assert (cfg.fft_layers, cfg.fft_kernel_size, cfg.fft_use_pos_embed, cfg.fft_use_last_norm) == (4, 9, 1, 1)   # base.yaml:68,72
 

@@ -48,11 +48,26 @@ def _vocoder(voc_sd, precision):
 
 
 @pytest.fixture(scope="module")
-def voc(voc_sd):
-    """the default (and benched) mode: fp16 ResBlock operands + split-operand serial convolutions"""
-    v = _vocoder(voc_sd, None)
-    assert v.precision == abi.VOC_F16
-    return v
+def _voc_f16(voc_sd):
+    from dict_tts_amd import vocoder
+    # PINNED to the benched mode: explicit precision (no automatic fallback) with the range guard on for EVERY call, so a
+    # clamped / overflowed fp16 activation raises inside the test instead of silently moving the suite to bf16x3
+    return vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="f16", range_guard=True)
+
+
+@pytest.fixture
+def voc(_voc_f16):
+    """the default (and benched) mode: fp16 ResBlock operands + split-operand serial convolutions.  The mode is asserted before AND
+    after every test that uses it."""
+    assert _voc_f16.precision == abi.VOC_F16 and _voc_f16._guard_left == -1 and _voc_f16._guard_raise
+    yield _voc_f16
+    assert _voc_f16.precision == abi.VOC_F16 and _voc_f16._guard_left == -1, "the vocoder left DTTS_VOC_F16 during the test"
+
+
+@pytest.fixture(scope="module")
+def voc_plain(voc_sd):
+    """DTTS_VOC_F16 exactly as bench.py builds it: explicit precision, NO range guard = the release (GUARD = false) kernel instantiations"""
+    return _vocoder(voc_sd, "f16")
 
 
 @pytest.fixture(scope="module")
@@ -145,13 +160,11 @@ def test_teacher_forced_mel2word_and_batch_padding_semantics(acoustic, oracle_sd
 
 def test_fused_prior_flow_equals_launch_by_launch(acoustic, monkeypatch):
     """the prior flow as one kernel (flowstack.hip: split-bf16 contractions, hardware exp2 / rcp in the gate) against the same flow launch by
-    launch on the generic exact-fp32 kernels (DTTS_TUNE bit 8, read when a context is created): same noise, same durations, mel within a
+    launch on the generic exact-fp32 kernels (dtts_config.tune_flags bit 8): same noise, same durations, mel within a
     tenth of the reference tolerance on every frame incl. the padded ones and the chunk seams (T_mel/4 > 96 rows: two chunks per utterance)"""
     from dict_tts_amd import model
-    monkeypatch.setenv("DTTS_TUNE", "256")
-    plain = model.PortaSpeech_dict(hparams={})
+    plain = model.PortaSpeech_dict(hparams={"dtts_tune_flags": 256})
     plain.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()}, strict=True)
-    monkeypatch.delenv("DTTS_TUNE")
     batch = synth.biaobei_batch(4, 6, gc.SEED)
     m2w = synth.teacher_mel2word(batch["word_tokens"], 45, 9)     # long utterances: 45 frames per word
     T_mel = m2w.shape[1] + (-m2w.shape[1]) % 4
@@ -238,11 +251,12 @@ def test_hifigan_ragged_batch_equals_per_utterance_oracle(voc, voc_x3, voc_bf16,
     assert float(full[0, 5 * 256:].abs().max()) == 0.0
 
 
-def test_hifigan_many_utterances_persistent_tiles(voc, oracle_voc_sd):
+def test_hifigan_many_utterances_persistent_tiles(voc, voc_plain, oracle_voc_sd):
     """the fused kernels' persistent workgroups walk the batch's valid tiles through a tile table (utterance -> tile count prefix sums):
     70 utterances, lengths 0..61 incl. empty and one-frame ones, enough tiles that every workgroup takes several — each row of the
     batched output is BIT-identical to the same utterance run alone (same tile origins), zero past its end, and within the waveform
     gate of the oracle"""
+    assert voc.precision == abi.VOC_F16 and voc._guard_raise   # the benched mode, guard on: a clamp raises
     from oracle import hifigan_ref as href
     rng = np.random.RandomState(7)
     lens = [0, 1, 61, 2, 33] + [int(v) for v in rng.randint(0, 62, size=65)]
@@ -253,6 +267,9 @@ def test_hifigan_many_utterances_persistent_tiles(voc, oracle_voc_sd):
             mel[i, :n] = synth.random_mel(300 + i, n, f"many{i}")
     full = voc.forward_batch(T(mel).cuda(), torch.tensor(lens, dtype=torch.int32)).cpu().numpy()
     assert np.isfinite(full).all()
+    # the unguarded instantiations (what bench.py times) compute the same bits as the guarded ones
+    assert voc_plain.precision == abi.VOC_F16 and voc_plain._guard_left == 0
+    assert np.array_equal(full, voc_plain.forward_batch(T(mel).cuda(), torch.tensor(lens, dtype=torch.int32)).cpu().numpy())
     for i, n in enumerate(lens):
         assert float(np.abs(full[i, n * 256:]).max(initial=0.0)) == 0.0
         if n == 0:
@@ -315,6 +332,7 @@ def test_fused_resblock_equals_unfused(voc_bf16, voc_bf16_unfused, oracle_voc_sd
 def test_config4_long_form_1000_chars(acoustic, oracle_sd, voc, oracle_voc_sd):
     """BASELINE.json configs[3]: 1000-char input (T_w = 1002), teacher-forced 5 frames/char -> ~5k mel frames, B=1:
     attention over 1002 words, every conv tiled over 5k..1.28M time steps, mel and waveform vs the oracle"""
+    assert voc.precision == abi.VOC_F16 and voc._guard_raise   # the benched mode, guard on: a clamp raises
     from oracle import dict_tts_ref as ref
     from oracle import hifigan_ref as href
     st = synth.biaobei_struct()
@@ -467,13 +485,14 @@ def test_device_int16_conversion_vs_reference_save_wav_golden(voc, golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[1] at full size
-def test_config2_batch60_full_size_vs_oracle(acoustic, oracle_sd, voc, oracle_voc_sd):
+def test_config2_batch60_full_size_vs_oracle(acoustic, oracle_sd, voc, voc_plain, oracle_voc_sd):
     """BASELINE.json configs[1] at its real size: the first 60 Biaobei sentences as ONE batch (T_w = 27, L_k = 148).
     (1) predicted durations: integer mel2word exact, pinyin strings identical, mel <= 1e-3 on every frame (the decoder
         runs unmasked over the padded batch, SURVEY 0.3, so padding leakage at B = 60 is part of the comparison);
     (2) teacher-forced 22 frames / char (T_mel = 740, the bench shape): mel <= 1e-3 on all 60 x 740 frames, and the
         waveform gates RMS(gpu - ref), |RMS(gpu) - RMS(ref)| <= 1e-4 end to end (GPU mel -> GPU vocoder against oracle mel ->
         oracle vocoder) on the shortest, a middle and the longest utterance."""
+    assert voc.precision == abi.VOC_F16 and voc._guard_raise   # the benched mode, guard on: a clamp raises
     from dict_tts_amd.model import decode_pinyin_ids
     from oracle import dict_tts_ref as ref
     from oracle import hifigan_ref as href
@@ -520,6 +539,7 @@ def test_config2_batch60_full_size_vs_oracle(acoustic, oracle_sd, voc, oracle_vo
     lens = got["mel_lens"].cpu().numpy()
     assert np.array_equal(lens, (want["mel2word"] > 0).sum(1).numpy())
     wav = voc.forward_batch(got["mel_out"], got["mel_lens"]).cpu().numpy()
+    assert np.array_equal(wav, voc_plain.forward_batch(got["mel_out"], got["mel_lens"]).cpu().numpy())   # guarded == release kernels
     order = np.argsort(lens)
     for u in (int(order[0]), int(order[len(order) // 2]), int(order[-1])):
         n = int(lens[u])
@@ -532,6 +552,7 @@ def test_b1_waveform_covers_the_padded_frames(acoustic, oracle_sd, voc, oracle_v
     """the reference's inference is B = 1 and vocodes ALL T_mel frames of mel_out, including the <= 3 frames added by the
     padding to frames_multiple (they repeat the last word and are valid frames; tasks/tts/dict_tts.py:255): mel_lens
     counts them, run_inference writes T_mel * hop samples and the tail equals spec2wav(mel_out) of the oracle"""
+    assert voc.precision == abi.VOC_F16 and voc._guard_raise   # the benched mode, guard on: a clamp raises
     from scipy.io import wavfile
     from dict_tts_amd import infer
     from oracle import audio_ref
@@ -932,15 +953,14 @@ def test_integer_durations_exact_over_seeds(acoustic, oracle_sd):
 
 
 def test_two_product_upsampler_option_stays_inside_the_gate(voc_sd, oracle_voc_sd, monkeypatch):
-    """DTTS_TUNE bit 13 (off by default): ups.1 on fp16 operands with two MFMA products instead of three bf16 ones (vconv.hip H2) —
+    """dtts_config.tune_flags bit 13 (off by default): ups.1 on fp16 operands with two MFMA products instead of three bf16 ones (vconv.hip H2) —
     still inside the waveform gate (7e-5), and different from the default mode's result (the option really ran)."""
     from dict_tts_amd import vocoder
     from oracle import hifigan_ref as href
     mel = synth.random_mel(21, 96, "h2")
     want = href.spec2wav(oracle_voc_sd, synth.hifigan_config(), mel).numpy()
     base = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="f16").spec2wav(mel)
-    monkeypatch.setenv("DTTS_TUNE", "8192")
-    opt = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="f16").spec2wav(mel)
+    opt = vocoder.HifiGAN(state_dict=voc_sd, config={**synth.hifigan_config(), "dtts_tune_flags": 8192}, precision="f16").spec2wav(mel)
     wave_gate(base, want)
     wave_gate(opt, want)
     assert not np.array_equal(base, opt) and rms(base - want) < rms(opt - want)
@@ -964,7 +984,19 @@ def test_fp16_range_guard_fires_and_falls_back(voc_sd, oracle_voc_sd):
     assert v0.precision == abi.VOC_F16 and v0._guard_left == vocoder.HifiGAN.GUARD_CALLS
     for _ in range(vocoder.HifiGAN.GUARD_CALLS):
         v0.spec2wav(mel)
-    assert v0.precision == abi.VOC_F16 and v0._guard_left == 0 and v0._state_dict is None
+    assert v0.precision == abi.VOC_F16 and v0._guard_left == 0 and v0._auto_guard
+    # ... but overflow depends on the INPUT too: after the initial guarded calls every GUARD_EVERY-th call is guarded again.
+    # A mel far outside the training range (x 3e6) drives the healthy checkpoint's activations out of the fp16 range: the unguarded calls
+    # return garbage without a word, the sampled call notices, redoes itself in bf16x3 and the object keeps that mode
+    hot = mel * 3e6
+    for i in range(vocoder.HifiGAN.GUARD_EVERY - 1):
+        v0.spec2wav(hot)
+        assert v0.precision == abi.VOC_F16, i
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        w_hot = v0.spec2wav(hot)
+    assert v0.precision == abi.VOC_BF16X3 and any("fp16 range" in str(w.message) for w in ws)
+    assert np.array_equal(w_hot, vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision="bf16x3").spec2wav(hot))
     # scaled weights, explicit fp16 without the guard: runs, and returns a clipped / overflowed waveform without a word (what round 2
     # did for every caller; v * 0.1 < -65504 converts to -inf, so the damage is usually NaN, not a subtle error)
     v1 = vocoder.HifiGAN(state_dict=big, config=synth.hifigan_config(), precision="f16")
@@ -1082,3 +1114,153 @@ def test_bench_two_ranks_on_one_device_testset_sharding():
     meta = g["last_meta"]                                   # last chunk: sentences 120..199 -> 40 per rank
     assert len(meta) == 2 and meta[0][0] == meta[1][0] == 40 and min(meta[0][1], meta[1][1]) > 100
     assert "+allgather(mel)" in two["config"]["parallelism"] and one["mel_allgather"]["enabled"] is False
+
+
+# ------------------------------------------------------------------------------------------------ memory safety
+def _redzoned(t, pad_elems=4096, fill=float("nan")):
+    """a copy of tensor t on the GPU whose storage has `pad_elems` sentinel elements before and after it: (view, check) where check()
+    asserts that no kernel wrote into the borders"""
+    flat = torch.full((t.numel() + 2 * pad_elems,), fill, dtype=t.dtype, device="cuda")
+    view = flat[pad_elems:pad_elems + t.numel()].view(t.shape)
+    view.copy_(t)
+    sentinel = flat[:pad_elems].clone()
+
+    def check():
+        torch.cuda.synchronize()
+        lo, hi = flat[:pad_elems], flat[pad_elems + t.numel():]
+        same = lambda a: torch.equal(a.view(torch.int32 if a.element_size() == 4 else torch.int64),
+                                     sentinel.view(torch.int32 if a.element_size() == 4 else torch.int64))
+        assert same(lo) and same(hi), "a kernel wrote outside a caller-owned buffer"
+    return view, check
+
+
+@pytest.fixture(scope="module")
+def dbg_pair(voc_sd):
+    """the acoustic model and the benched vocoder mode in MEMORY-SAFETY mode (dtts_config.debug_redzone): every workspace buffer and weight
+    pack between 4 KiB red zones, workspaces 0xFF(NaN)-filled before each forward"""
+    from dict_tts_amd import model, vocoder
+    m = model.PortaSpeech_dict(hparams={"dtts_debug_redzone": 1})
+    m.load_state_dict({k: T(v) for k, v in synth.dict_tts_state_dict(gc.SEED, n_phone=6).items()}, strict=True)
+    v = vocoder.HifiGAN(state_dict=voc_sd, config={**synth.hifigan_config(), "dtts_debug_redzone": 1}, precision="f16")
+    return m, v
+
+
+def _clean(ctx, what):
+    n = ctx.debug_check(torch.cuda.current_stream().cuda_stream)
+    assert n == 0, f"{what}: {ctx.last_error()}"
+
+
+def test_memory_safety_harness_notices_a_damaged_red_zone(dbg_pair, voc_plain):
+    """the check itself: one byte written just past a workspace buffer is reported (and named), and a release context refuses the call"""
+    _, v = dbg_pair
+    s = torch.cuda.current_stream().cuda_stream
+    v.spec2wav(synth.random_mel(1, 8, "poke"))
+    _clean(v.ctx, "before the poke")
+    v.ctx.debug_poke(s)
+    assert v.ctx.debug_check(s) == 1 and "AFTER the buffer" in v.ctx.last_error() and "vocoder workspace buffer #0" in v.ctx.last_error()
+    v.spec2wav(synth.random_mel(1, 8, "poke"))   # the next forward refills the workspace
+    _clean(v.ctx, "after the refill")
+    with pytest.raises(abi.DttsError, match="debug_redzone"):
+        voc_plain.ctx.debug_check(s)
+
+
+def test_memory_safety_vocoder_shapes(dbg_pair, voc_plain):
+    """HifiGAN (DTTS_VOC_F16, the benched kernels) under red zones + NaN-poisoned workspaces on the shapes that stress the tile walkers: the
+    70-utterance ragged batch (empty / 1-frame rows, several tiles per persistent workgroup), B = 1 short (half-size tiles), the 5,012-frame
+    long form (1.28 M rows at the last stage), a B = 60 x 740 batch (the bench shape).  Per shape: no red zone damaged (no out-of-range
+    WRITE), the caller's mel / wav borders untouched, the waveform finite, zero past each utterance and BIT-identical to the release
+    context's (an out-of-range or stale READ that is consumed would read NaN here and something else there)."""
+    _, v = dbg_pair
+    rng = np.random.RandomState(7)
+    many = [0, 1, 61, 2, 33] + [int(x) for x in rng.randint(0, 62, size=65)]
+    cases = [("70 ragged utterances", many, 64), ("B=1 short", [37], 37), ("B=1, 3 frames", [3], 3), ("long form", [5012], 5012),
+             ("bench shape", [int(x) for x in rng.randint(250, 741, size=59)] + [740], 740)]
+    for name, lens, Tm in cases:
+        B = len(lens)
+        mel = np.zeros((B, Tm, 80), np.float32)
+        for i, n in enumerate(lens):
+            if n:
+                mel[i, :n] = synth.random_mel(900 + i, n, f"ms{name}{i}") if n < 2000 else np.tile(synth.random_mel(900, 179, "ms.long"), (28, 1))[:n]
+        mel_d, chk_mel = _redzoned(T(mel))
+        wav_d, chk_wav = _redzoned(torch.zeros(B, Tm * 256))
+        lens_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        v.ctx.hifigan_forward(mel_d.data_ptr(), lens_d.data_ptr(), B, Tm, wav_d.data_ptr(), s)
+        _clean(v.ctx, name)
+        chk_mel()
+        chk_wav()
+        got = wav_d.cpu().numpy()
+        assert np.isfinite(got).all(), name
+        for i, n in enumerate(lens):
+            assert not got[i, n * 256:].any(), (name, i)
+        want = voc_plain.forward_batch(T(mel).cuda(), lens_d).cpu().numpy()
+        assert np.array_equal(got, want), name
+
+
+def test_memory_safety_text2mel_shapes(dbg_pair, acoustic):
+    """the acoustic model under the same mode: B = 60 at full size (tensor API and the resident-table id path), the 1000-character long form,
+    B = 1 — red zones intact after encode and after decode, every output finite and BIT-identical to the release context's"""
+    m, _ = dbg_pair
+    st = synth.biaobei_struct()
+    s = torch.cuda.current_stream().cuda_stream
+    keys = ("mel_out", "dur", "word_encoder_out", "pron_attn", "dict_attn", "mel2word")
+
+    def same(a, b, name):
+        for k in keys:
+            x, y = a[k].cpu(), b[k].cpu()
+            assert x.shape == y.shape and torch.isfinite(x.float()).all(), (name, k)
+            assert torch.equal(x, y), (name, k, float((x.float() - y.float()).abs().max()))
+
+    ids1000 = [w for sent in st["sentences"] for w in sent][:1000]
+    for name, sents, tf in (("B=60", st["sentences"][:60], None), ("B=1", [st["sentences"][5]], None), ("long form", [ids1000], (5, 5))):
+        batch = synth.make_batch(sents, gc.SEED)
+        m2w = None if tf is None else T(synth.teacher_mel2word(batch["word_tokens"], *tf))
+        B = batch["word_tokens"].shape[0]
+        # the same noise for both contexts: z_p is passed explicitly (its length from a first, untimed pass when the durations are predicted)
+        T_mel = _run(acoustic, batch)["mel_out"].shape[1] if m2w is None else m2w.shape[1] + (-m2w.shape[1]) % 4
+        z = T(synth.noise(77, B, T_mel // 4, "ms.z"))
+        want = _run(acoustic, batch, z=z, mel2word=m2w)
+        got = _run(m, batch, z=z, mel2word=m2w)
+        _clean(m.ctx, name)
+        same(got, want, name)
+    # the resident dictionary (pre-projected rows, weight-pack red zones around the table) + ids
+    table = synth.dict_table(gc.SEED)
+    m.upload_dict_table(table)
+    acoustic.upload_dict_table(table)
+    ib = synth.make_id_batch(st["sentences"][:60], table)
+    probe = acoustic.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"])
+    z = T(synth.noise(78, 60, probe["mel_out"].shape[1] // 4, "ms.zi"))
+    want = acoustic.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"], z_p=z)
+    got = m.forward_ids(T(ib["word_tokens"]), T(ib["entry_ids"]), T(ib["pron_modified"]), ib["L_k"], ib["P"], z_p=z)
+    _clean(m.ctx, "id path B=60")
+    same(got, want, "id path B=60")
+
+
+def test_memory_safety_other_kernel_families(voc_sd):
+    """the generic convolution kernels (DTTS_VOC_BF16X3), the all-bf16 vocoder and the FFT-block stack under the same mode"""
+    from dict_tts_amd import fft, vocoder
+    s = torch.cuda.current_stream().cuda_stream
+    lens = [5, 33, 17, 64, 1, 0]
+    mels = [synth.random_mel(100 + i, n, f"rag{i}") for i, n in enumerate(lens) if n]
+    for prec in ("bf16x3", "bf16"):
+        v = vocoder.HifiGAN(state_dict=voc_sd, config={**synth.hifigan_config(), "dtts_debug_redzone": 1}, precision=prec)
+        ref = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision=prec)
+        got, want = v.spec2wav_batch(mels), ref.spec2wav_batch(mels)
+        _clean(v.ctx, prec)
+        for a, b in zip(got, want):
+            assert np.isfinite(a).all() and np.array_equal(a, b), prec
+    cfg = gc.G8_CASES["dec"]
+    sd = {k: T(x) for k, x in synth.fft_blocks_state_dict(gc.SEED + 1, 192, **cfg).items()}
+    x = synth.randn(gc.SEED, "fft.ms.x", (5, 300, 192), 1.0)
+    pm = torch.zeros(5, 300, dtype=torch.bool)
+    for b, n in enumerate([300, 257, 64, 33, 1]):
+        x[b, n:] = 0
+        pm[b, n:] = True
+    outs = []
+    for hp in ({"dtts_debug_redzone": 1}, {}):
+        f = fft.FFTBlocks(192, cfg["layers"], ffn_kernel_size=9, num_heads=2, hparams=hp)
+        f.load_state_dict(sd)
+        outs.append(f(T(x), padding_mask=pm).cpu())
+        if hp:
+            _clean(f.ctx, "fft blocks")
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

@@ -1,6 +1,10 @@
 #!/bin/bash
 # same-box A/B of DTTS_TUNE settings on the vocoder micro-benchmark (run on the GPU box): tools/ab_tune.sh <rounds> <tuneA> <tuneB> ... [trace]
 # alternates the settings through tools/voc_bench.py; with a last argument "trace" also one rocprofv3 kernel trace per setting
+# DTTS_TUNE is honoured only by the ablation build (make -C dict_tts_amd/csrc ablate -> dict_tts_amd/libdicttts_abl.so): it is swapped in here
+cp dict_tts_amd/libdicttts_hip.so /tmp/rel.so
+cp dict_tts_amd/libdicttts_abl.so dict_tts_amd/libdicttts_hip.so || exit 1
+trap 'cp /tmp/rel.so dict_tts_amd/libdicttts_hip.so' EXIT
 N=$1; shift
 TR=""; ARGS=()
 for a in "$@"; do if [ "$a" = "trace" ]; then TR=1; else ARGS+=("$a"); fi; done
