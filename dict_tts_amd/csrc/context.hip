@@ -2286,24 +2286,29 @@ int dtts_debug_check(dtts_handle h, int64_t* damaged_bytes, dtts_stream stream) 
     HIPCHK(hipStreamSynchronize(s));
     std::vector<RzZone> zones;
     std::vector<std::string> names;
-    auto add = [&](const char* base, size_t start, size_t bytes, size_t limit, const std::string& name) {   // the zones before and after one buffer
-        zones.push_back({(const unsigned char*)base + start - RZ, (unsigned)RZ, (unsigned)names.size()});
-        names.push_back(name + ": zone BEFORE the buffer");
-        const size_t tail = std::min(RZ, limit - (start + bytes));
-        zones.push_back({(const unsigned char*)base + start + bytes, (unsigned)tail, (unsigned)names.size()});
-        names.push_back(name + ": zone AFTER the buffer");
+    auto zone = [&](const char* p0, size_t n, const std::string& name) {
+        if (!n) return;
+        zones.push_back({(const unsigned char*)p0, (unsigned)n, (unsigned)names.size()});
+        names.push_back(name);
     };
     const std::pair<const char*, Arena*> arenas[] = {{"encode workspace", &h->a_enc}, {"decode workspace", &h->a_dec}, {"vocoder workspace", &h->a_voc}, {"fft workspace", &h->a_fft}};
-    for (const auto& a : arenas)
-        for (size_t i = 0; i < a.second->bufs.size(); ++i) {
-            const auto& b = a.second->bufs[i];
-            const size_t limit = i + 1 < a.second->bufs.size() ? a.second->bufs[i + 1].start - RZ + RZ : a.second->cap;   // (the next buffer's own front zone follows)
-            add(a.second->base, b.start, b.bytes, std::min(limit, a.second->cap), std::string(a.first) + " buffer #" + std::to_string(i) + " (" + std::to_string(b.bytes) + " B)");
+    for (const auto& a : arenas) {
+        const auto& bufs = a.second->bufs;
+        const char* base = a.second->base;
+        for (size_t i = 0; i < bufs.size(); ++i) {   // layout: [RZ][buffer 0][slack to 256 B][RZ][buffer 1]...[RZ .. up to the arena's end]
+            const std::string me = std::string(a.first) + " buffer #" + std::to_string(i) + " (" + std::to_string(bufs[i].bytes) + " B)";
+            const size_t end = bufs[i].start + bufs[i].bytes, padded_end = bufs[i].start + ((bufs[i].bytes + 255) & ~(size_t)255);
+            zone(base + bufs[i].start - RZ, RZ, i ? "AFTER " + std::string(a.first) + " buffer #" + std::to_string(i - 1) + " / BEFORE " + me : "BEFORE " + me);
+            zone(base + end, padded_end - end, "AFTER " + me + " (alignment slack)");
+            if (i + 1 == bufs.size()) zone(base + padded_end, std::min(RZ, a.second->cap - padded_end), "AFTER " + me);
         }
+    }
     for (size_t i = 0; i < h->rz_static.size(); ++i) {
         const auto& b = h->rz_static[i];
         const size_t padded = (b.bytes + 255) & ~(size_t)255;
-        add(b.p, 0, b.bytes, padded + RZ, "weight pack / table #" + std::to_string(i) + " (" + std::to_string(b.bytes) + " B)");
+        const std::string me = "weight pack / table #" + std::to_string(i) + " (" + std::to_string(b.bytes) + " B)";
+        zone(b.p - RZ, RZ, "BEFORE " + me);
+        zone(b.p + b.bytes, padded + RZ - b.bytes, "AFTER " + me);
     }
     if (zones.empty()) {
         *damaged_bytes = 0;
