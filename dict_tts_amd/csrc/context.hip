@@ -1068,7 +1068,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     } span{h, nullptr};
     if (h->timers[TV].enabled && !(h->tune & 16)) {
         span.t = new Timed(h, TV, s);
-        h->timers[TV].launches -= 1;   // (the span itself is not a launch)
+        if (span.t->e1) h->timers[TV].launches -= 1;   // (the span itself is not a launch; e1 is null when no event could be created)
         h->voc_span = true;
     }
     const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)

@@ -611,6 +611,17 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int rows = (TT - 1) * p.stride + (p.K - 1) * p.dil + 1;
     const size_t lds = (size_t)rows * PITCH * (ENGINE == ENG_BF16X3 ? 2 : 1);
     auto kern = conv1d_cl_kernel<ENGINE, MT, NT, WT, WC, CK>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit (the strided g_pre_net on this kernel: ~140 KB): opt in, per device
+        static bool configured_dev[64] = {};
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        if (!configured_dev[cur_dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            configured_dev[cur_dev & 63] = true;
+        }
+    }
     dim3 grid((p.T_out + TT - 1) / TT, (p.C_out_pad + CO_T - 1) / CO_T, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
