@@ -1154,10 +1154,34 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 rp.el = el;
                 rp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                 rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
+                rp.no_pingpong = (h->tune & 128) ? 1 : 0;   // tune bit 7: rblock.hip's lockstep form everywhere (A/B)
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
-                Timed tm(h, TV, s);
-                LAUNCH(rblock_launch(rp, ch, s));
+#ifdef DTTS_ABLATE
+                static unsigned long long* rstats = nullptr;
+                if (ablate_env("DTTS_RB_STATS")) {   // per-phase cycle sums of rblock2's two groups, printed per launch
+                    if (!rstats) hipMalloc((void**)&rstats, 18 * sizeof(unsigned long long));
+                    hipMemsetAsync(rstats, 0, 18 * sizeof(unsigned long long), s);
+                    rp.stats = rstats;
+                }
+#endif
+                {
+                    Timed tm(h, TV, s);
+                    LAUNCH(rblock_launch(rp, ch, s));
+                }
+#ifdef DTTS_ABLATE
+                if (rp.stats) {
+                    unsigned long long hs[18];
+                    hipStreamSynchronize(s);
+                    hipMemcpy(hs, rp.stats, sizeof hs, hipMemcpyDeviceToHost);
+                    for (int g = 0; g < 2 && hs[8]; ++g) {
+                        const double n = hs[g * 9 + 8] ? (double)hs[g * 9 + 8] : 1.0;
+                        const unsigned long long* a = hs + g * 9;
+                        fprintf(stderr, "rblock2 C=%d K=%d grp %d tiles=%llu cycles/tile: write_x %.0f  bar_after_N %.0f  conv1 %.0f  bar_after_M %.0f  rewrite_xt %.0f  conv2 %.0f  rewrite_x %.0f  epilogue %.0f\n",
+                                ch, rp.K, g, a[8], a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n);
+                    }
+                }
+#endif
                 continue;
             }
             if (fuse && vpair_supported(ch, c1[0].K, c1[0].dil) && vpair_supported(ch, c1[2].K, c1[2].dil) && c1[0].C_in_pad == ch) {

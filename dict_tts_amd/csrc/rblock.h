@@ -28,11 +28,16 @@ struct RBlockParams {
     unsigned* tile_ctr;    // persistent configurations: device counter (zero at launch) for dynamic tile claiming, or null = static w, w + G, ...
     int pre_off;           // (set by the launcher) byte offset of the tile-count table in dynamic LDS
     unsigned long long* ovf;   // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null
+    int no_pingpong;       // 1: never take the phase-shifted two-group form (rblock2.hip) — dtts_config.tune_flags bit 7, A/B
+    unsigned long long* stats;   // -DDTTS_ABLATE builds only (DTTS_RB_STATS): per-phase cycle sums of each group's wave 0 (rblock2.hip)
     int dbg;               // -DDTTS_ABLATE builds only; tuning ablations (DTTS_VCONV_DBG): 1 skip contractions, 2 skip epilogue, 4 skip the x load, 8 skip write_act
 };
 
 bool rblock_supported(int C, int K);
 int rblock_padded_taps(int C, int K);
 hipError_t rblock_launch(const RBlockParams& p, int C, hipStream_t stream);
+// rblock2.hip: two phase-shifted groups of waves per workgroup (one computing while the other rewrites / loads / stores)
+bool rblock2_supported(int C, int K, bool wav);
+hipError_t rblock2_launch(const RBlockParams& p, int C, hipStream_t stream);
 
 } // namespace dtts

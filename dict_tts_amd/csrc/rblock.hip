@@ -491,6 +491,8 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
         const int tt = W - 12 * (p.K - 1) - (p.wav ? 6 : 0);
         return small_ok && tt >= 32 && 2 * (long long)p.B * ((p.T + tt - 1) / tt) <= cus;
     };
+    // C = 32 without the fused conv_post: two phase-shifted groups per workgroup, a 512-row tile each (rblock2.hip)
+    if (!p.no_pingpong && rblock2_supported(C, p.K, p.wav != nullptr) && !few(512)) return rblock2_launch(p, C, stream);
     if (C == 32 && rb32 && p.K >= 7 && !few(1024)) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
     if (C == 64 && few(512)) return rb_launch_cfg<64, 4, 1, 2, 2, EL, 1>(p, stream);     // 256-row tile, 4 waves
     if (C == 128 && few(256)) return rb_launch_cfg<128, 4, 1, 1, 4, EL, 1>(p, stream);   // 128-row tile, 4 waves

@@ -17,9 +17,10 @@ ap.add_argument("--B", type=int, default=60)
 ap.add_argument("--T", type=int, default=740)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--precision", default="f16")
+ap.add_argument("--tune", type=int, default=0, help="dtts_config.tune_flags (A/B switches, include/dicttts_hip.h)")
 a = ap.parse_args()
 T_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
-voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config(),
+voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config={**synth.hifigan_config(), "dtts_tune_flags": a.tune},
                       precision=abi.VOC_PRECISIONS[a.precision])
 voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
 rng = np.random.default_rng(0)
