@@ -213,6 +213,7 @@ def main():
                          "full: no budget, B=60 batched variant")
     ap.add_argument("--cpu-budget", type=float, default=420.0, help="seconds the 'protocol' CPU leg may spend on its repetitions")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures / per-stage / second-mode measurements")
+    ap.add_argument("--voc-tune", type=int, default=0, help="dtts_config.tune_flags of the vocoder context (A/B switches, include/dicttts_hip.h)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the vocoder on the text->mel stream (default: vocoder of batch i on a second HIP stream, "
                          "overlapping text->mel of batch i+1; every batch is still fully processed inside the timed region)")
@@ -260,7 +261,8 @@ def main():
     m = model.PortaSpeech_dict(hparams={})
     m.load_state_dict({k: T(v) for k, v in sd_np.items()})
     voc_sd = {k: T(v) for k, v in synth.hifigan_state_dict(1234).items()}
-    voc = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision=abi.VOC_PRECISIONS[args.precision])
+    voc = vocoder.HifiGAN(state_dict=voc_sd, config={**synth.hifigan_config(), "dtts_tune_flags": args.voc_tune},
+                          precision=abi.VOC_PRECISIONS[args.precision])
     voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
     hop = voc.hop
     # ---- the dictionary: resident in HBM, uploaded once (not part of a step)

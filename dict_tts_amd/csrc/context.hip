@@ -130,6 +130,7 @@ struct dtts_ctx {
     std::vector<void*> allocs;
     bool debug_rz = false;                                   // dtts_config.debug_redzone
     int device = 0;                                          // the HIP device that was current at dtts_create: weights and workspaces live there
+    int n_cu = 256;                                          // its compute units
     struct StaticBuf { char* p; size_t bytes; };
     std::vector<StaticBuf> rz_static;                         // debug: weight packs / tables (user pointer, payload bytes) between red zones
     bool acoustic_ready = false, vocoder_ready = false, fft_ready = false;
@@ -1027,12 +1028,42 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         }
     }
     const int melC = h->conv_pre.C_in_pad;
-    HIPCHK(h->a_voc.reserve(max_elems * (4 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
+    const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)
+    // which stages run ALL their ResBlocks in one launch (rblock.hip; OPT-IN, tune bit 9 — measured: HBM traffic -0.36 MB / mel frame, vocoder
+    // alone +1.1 %, pipelined step +1.9 %: LABNOTES round 4): C <= 64, every ResBlock has a whole-ResBlock kernel, and the batch has at least
+    // two tiles per CU (small grids keep one launch per ResBlock: half-size tiles fill the chip there)
+    bool fuse_stage[8] = {};
+    size_t s_elems = max_elems;   // capacity of the stage-sum buffer
+    {
+        long long rows = T;
+        int ch = c.upsample_initial_channel;
+        for (int i = 0; i < nup; ++i) {
+            rows *= c.upsample_rates[i];
+            ch /= 2;
+            bool all = fuse && (h->tune & 512) && nk >= 2 && nk <= 3 && (ch == 32 || ch == 64);
+            int kmax = 0;
+            for (int j = 0; j < nk && all; ++j) {
+                all = !h->rbf1[(size_t)i * nk + j].empty();
+                if (all) kmax = std::max(kmax, h->rbf1[(size_t)i * nk + j][0].K);
+            }
+            if (!all) continue;
+            const int W = ch == 32 ? 1024 : 512, TT = W - 12 * (kmax - 1);
+            if (TT < 64 || (long long)B * ((rows + TT - 1) / TT) < 2LL * h->n_cu) continue;
+            if (i == nup - 1 && h->post_w) {   // with the fused conv_post the tiles overlap: one private strip of the stage sum per tile
+                const long long prow = rblock_private_rows(ch, kmax, B, (int)rows);
+                if (prow <= 0 || (size_t)prow * ch * sizeof(float) >= (size_t)INT_MAX) continue;
+                s_elems = std::max(s_elems, (size_t)prow * ch);
+            }
+            fuse_stage[i] = true;
+        }
+    }
+    const size_t s_cap_bytes = s_elems * sizeof(float);
+    HIPCHK(h->a_voc.reserve((s_elems - max_elems) * sizeof(float) + max_elems * (4 * sizeof(float) + 4 * sizeof(bf)) + (size_t)B * T * melC * sizeof(bf) +
                             (size_t)(nup + 2) * B * sizeof(int) + (64 << 10), s));
     Arena& A = h->a_voc;
     float* Xf = A.alloc<float>(max_elems);
     float* Rf = A.alloc<float>(max_elems);
-    float* Sf = A.alloc<float>(max_elems);
+    float* Sf = A.alloc<float>(s_elems);
     float* Rg = A.alloc<float>(max_elems);   // second ping-pong buffer of the fused-iteration path (vpair.hip)
     bf* Xa = A.alloc<bf>(max_elems);
     bf* Ra = A.alloc<bf>(max_elems);
@@ -1071,7 +1102,6 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         if (span.t->e1) h->timers[TV].launches -= 1;   // (the span itself is not a launch; e1 is null when no event could be created)
         h->voc_span = true;
     }
-    const bool fuse = exact || !c.vocoder_unfused;   // vocoder_unfused: per-convolution kernels (a testing aid of the bf16 mode)
     bool post_done = false;
     int Tcur = T, ch = c.upsample_initial_channel;
     if (exact) {   // conv_pre: mel fp32 in, fp32 out
@@ -1129,32 +1159,50 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 rp.lens = lout;
                 rp.B = B;
                 rp.T = Tcur;
-                rp.K = f1[0].K;
-                rp.Kp = rblock_padded_taps(ch, f1[0].K);
-                for (int mth = 0; mth < 3; ++mth) {
-                    rp.w1[mth] = (const uint4*)f1[mth].w_hi;
-                    rp.w2[mth] = (const uint4*)f2[mth].w_hi;
-                    rp.b1[mth] = f1[mth].bias;
-                    rp.b2[mth] = f2[mth].bias;
-                    rp.dil[mth] = f1[mth].dil;
+                auto fill_set = [&](RBlockParams::Set& st, int jj) {
+                    const auto& g1 = h->rbf1[(size_t)i * nk + jj];
+                    const auto& g2 = h->rbf2[(size_t)i * nk + jj];
+                    st.K = g1[0].K;
+                    st.Kp = rblock_padded_taps(ch, g1[0].K);
+                    for (int mth = 0; mth < 3; ++mth) {
+                        st.w1[mth] = (const uint4*)g1[mth].w_hi;
+                        st.w2[mth] = (const uint4*)g2[mth].w_hi;
+                        st.b1[mth] = g1[mth].bias;
+                        st.b2[mth] = g2[mth].bias;
+                        st.dil[mth] = g1[mth].dil;
+                    }
+                };
+                // ALL ResBlocks of a C <= 64 stage in ONE launch (rblock.hip: work items (tile, ResBlock)): x crosses HBM once per tile and the
+                // stage sum is accumulated through L2 / Infinity Cache.  Opt-in: tune bit 9
+                const bool stage_fused = fuse_stage[i];
+                if (stage_fused && j > 0) continue;        // (launched with j = 0)
+                const int j_last = stage_fused ? nk - 1 : j;
+                rp.nrb = stage_fused ? nk : 1;
+                rp.K = 0;
+                for (int jj = j; jj <= j_last; ++jj) {
+                    fill_set(rp.rb[jj - j], jj);
+                    rp.K = std::max(rp.K, rp.rb[jj - j].K);
                 }
+                (void)f1;
+                (void)f2;
                 rp.mode = j == 0 ? 0 : (j == nk - 1 ? 2 : 1);
                 if (nk == 1) rp.mode = 2;
                 rp.div = (float)nk;
                 rp.slope = last_stage ? 0.01f : 0.1f;
                 rp.Sa = exact ? nullptr : Sa;
                 rp.drop_S = exact ? 0 : 1;   // bf16 mode: after a stage only its bf16 leaky_relu copy is consumed (by ups[i+1] / conv_post)
-                if (last_stage && j == nk - 1 && h->post_w) {   // conv_post + tanh in this kernel's epilogue: the stage output stays on chip
+                if (last_stage && j_last == nk - 1 && h->post_w) {   // conv_post + tanh in this kernel's epilogue: the stage output stays on chip
                     rp.wav = wav;
                     rp.post_w = h->post_w;
                     rp.post_b = h->post_b;
                     rp.Sa = nullptr;
                     post_done = true;
+                    if (stage_fused) rp.s_private = (int)std::min<size_t>(s_cap_bytes, (size_t)INT_MAX);   // one private strip of S per tile (the tiles overlap)
                 }
                 rp.el = el;
                 rp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                 rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
-                rp.no_pingpong = (h->tune & 128) ? 1 : 0;   // tune bit 7: rblock.hip's lockstep form everywhere (A/B)
+                rp.pingpong = (h->tune & 128) ? 1 : 0;   // tune bit 7: the two-group form of rblock2.hip (experiment)
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
 #ifdef DTTS_ABLATE
@@ -1374,6 +1422,7 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
     }
     h->guard_on = cfg->vocoder_range_guard != 0;
     (void)hipGetDevice(&h->device);
+    if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     h->debug_rz = cfg->debug_redzone != 0;
     h->a_fft.debug = h->a_enc.debug = h->a_dec.debug = h->a_voc.debug = h->debug_rz;
     *out = h;

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }
 
     const int kg_stride = (C / 32) * 64;
-    const int S = DTTS_DBG(p, 1) ? 0 : p.Kp * NKG;  // packed taps (zero padded so that S % 4 == 0)
+    // work items of a workgroup: (tile, ResBlock r) — r runs over the launch's p.nrb ResBlocks on the SAME tile before the next tile
+    int r = 0;
 
 #pragma unroll 1
     for (;;) {
@@ -172,6 +173,14 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }
     const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const size_t wlane = (size_t)(wc * NT) * 64 + lane;
+    r = __builtin_amdgcn_readfirstlane(r);
+    const RBlockParams::Set& R = p.rb[r];
+    const int Kr = R.K;                              // this ResBlock's kernel size (the tile's halo follows the launch's largest)
+    const int S = DTTS_DBG(p, 1) ? 0 : R.Kp * NKG;   // packed taps (zero padded so that S % 4 == 0)
+    const bool last_rb = r + 1 == p.nrb;
+    // what the epilogue does with the stage sum: one ResBlock per launch: p.mode; all of the stage's: write, accumulate.., finish
+    const int mode = p.nrb == 1 ? p.mode : (r == 0 ? 0 : (last_rb ? 2 : 1));
+    const bool wav_now = p.wav && last_rb;
     t0 = __builtin_amdgcn_readfirstlane(t0);
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;
@@ -182,11 +191,19 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // tiles instead of setting the launch's finish time.  One lane issues the atomic at the top of the tile; its result is not
     // needed before the epilogue (the x prefetch), where it is broadcast through LDS behind a barrier that exists anyway.
     unsigned claim = 0;
-    if (PS && p.tile_ctr && tid == 0) claim = atomicAdd(p.tile_ctr, 1u);
+    if (PS && p.tile_ctr && tid == 0 && last_rb) claim = atomicAdd(p.tile_ctr, 1u);
     int jn = j + G;
     bool has_next = PS && jn < total;
     int bn = b, lenn = len, t0n = 0;
     auto plan_next = [&]() {
+        if (!last_rb) {                              // the same tile again, for the stage's next ResBlock
+            has_next = true;
+            jn = j;
+            bn = b;
+            lenn = len;
+            t0n = t0;
+            return;
+        }
         has_next = PS && jn < total;
         bn = b;
         if (has_next) {
@@ -195,9 +212,13 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             t0n = (jn - pre[bn]) * TTo - (p.wav ? PH : 0);
         }
     };
-    if (!(PS && p.tile_ctr)) plan_next();
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
-    const int goff0 = ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
+    if (!(PS && p.tile_ctr) || !last_rb) plan_next();
+    // the stage sum: [B][T][C] like x — or, p.s_private (all ResBlocks in one launch WITH the fused conv_post, whose tiles overlap by
+    // 2 PH rows): a private strip of TT rows per tile, so that no two workgroups read-modify-write the same rows
+    const auto rs_s = p.s_private ? __builtin_amdgcn_make_buffer_rsrc((void*)p.S, 0, p.s_private, 0x00020000)
+                                  : __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
+    const int goff0 = p.s_private ? ((j * TT - H + r0) * C + c4 * 4) * 4
+                                  : ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
 
     // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance.
     // bias: this lane's 4 channel quads per co-tile, loaded into registers BEFORE the contraction it follows.
@@ -236,8 +257,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 
     uint4 ring[4][NT];
     f32x4 bb[NT][4];   // one live bias set
-    rb_preload<NT>(ring, p.w1[0] + wlane, kg_stride);   // in flight during the first activation write
-    load_bias(bb, p.b1[0]);
+    rb_preload<NT>(ring, R.w1[0] + wlane, kg_stride);   // in flight during the first activation write
+    load_bias(bb, R.b1[0]);
     write_act(xr);
     __syncthreads();
 
@@ -252,10 +273,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
-        load_bias(bb, p.b2[it]);       // lands while conv1 runs
-        const int d = p.dil[it];
-        rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
-        rb_preload<NT>(ring, p.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
+        load_bias(bb, R.b2[it]);       // lands while conv1 runs
+        const int d = R.dil[it];
+        rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
+        rb_preload<NT>(ring, R.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
         write_act(acc);                // xt (bf16, activated) overwrites it
         __syncthreads();
@@ -268,10 +289,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
-        if (it < 2) load_bias(bb, p.b1[it + 1]);
-        rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, kg_stride);
-        if (it < 2) rb_preload<NT>(ring, p.w1[it + 1] + wlane, kg_stride);
-        if (PS && p.tile_ctr && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
+        if (it < 2) load_bias(bb, R.b1[it + 1]);
+        rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
+        if (it < 2) rb_preload<NT>(ring, R.w1[it + 1] + wlane, kg_stride);
+        if (PS && p.tile_ctr && last_rb && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
         __syncthreads();               // every wave is done reading xt
         if (it < 2) {
             write_act(xr);
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         }
     }
 
-    if (PS && p.tile_ctr) {
+    if (PS && p.tile_ctr && last_rb) {
         jn = __builtin_amdgcn_readfirstlane(pre[3 * p.B + 1]);
         plan_next();
     }
@@ -305,13 +326,15 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             sold[m][u] = u32x4{0u, 0u, 0u, 0u};
-            if (p.mode >= 1) sold[m][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, VP_LD_AUX);
+            // (all ResBlocks in one launch: the sum was written by THIS workgroup a moment ago and sits in L2 / Infinity Cache: a cached read)
+            if (mode >= 1) sold[m][u] = p.nrb > 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0)
+                                                  : __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, VP_LD_AUX);
         }
     // fused conv_post: the stage output leaky_relu(xs / num_kernels) stays in LDS as an fp32 tile ([TT rows][C], rows outside
     // the utterance zero = conv_post's zero padding) instead of going to HBM; the transposition buffer moves behind it
     constexpr int OP = C * 4;                      // otile row pitch (bytes)
     char* otile = smem;
-    char* estage = p.wav ? smem + (((size_t)TT * OP > (size_t)(W + 2 * RB_GUARD) * PITCH) ? (size_t)TT * OP : (size_t)(W + 2 * RB_GUARD) * PITCH) : stage;
+    char* estage = wav_now ? smem + (((size_t)TT * OP > (size_t)(W + 2 * RB_GUARD) * PITCH) ? (size_t)TT * OP : (size_t)(W + 2 * RB_GUARD) * PITCH) : stage;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (m) __syncthreads();
@@ -333,7 +356,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             const int off = eoff(m, u);
             f32x4 o = *(const f32x4*)(estage + (r0 + RPP * u) * EP + c4 * 16);
             o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
-            if (p.wav) {
+            if (wav_now) {
                 const int row = tile_row(m, u);                        // local tile row
                 if (row >= H && row < H + TT) {
                     const int t = base_t + row;
@@ -343,20 +366,23 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 }
                 continue;
             }
-            if (p.mode == 2) {
+            if (mode == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
-            if (!(p.mode == 2 && p.Sa && p.drop_S))   // the stage's consumers read only the bf16 copy: the fp32 sum can stay unwritten
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, VP_ST_AUX);
-            if (p.mode == 2 && p.Sa) {
+            if (!(mode == 2 && p.Sa && p.drop_S)) {   // the stage's consumers read only the bf16 copy: the fp32 sum can stay unwritten
+                // an intermediate sum of a fused launch is re-read by this workgroup's next ResBlock: write-back cached; final results stream out
+                if (p.nrb > 1 && !last_rb) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_s, off, 0, VP_ST_AUX);
+            }
+            if (mode == 2 && p.Sa) {
                 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
                 __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
         }
     }
-    if constexpr (C == 32) if (p.wav) {   // (the launcher rejects p.wav for other widths)
+    if constexpr (C == 32) if (wav_now) {   // (the launcher rejects p.wav for other widths)
         // ---- wav[t] = tanh(b + sum_{tap, c} w[c][tap] * otile[t + tap - 3][c])   (conv_post + tanh, hifigan.py:139-141) in exact fp32:
         // 8 lanes per output sample (4 channels each, 7 taps), partial sums joined by three xor-shuffles
         __syncthreads();
@@ -388,7 +414,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);
     }
     if (!has_next) break;
-    if (p.wav) {
+    r = last_rb ? 0 : r + 1;
+    if (wav_now) {
         // the fp32 output tile aliases the activation buffer AND its guard bands: conv_post's reads are over behind this barrier, then
         // the bands are zero again before the next tile's first convolution reads them (the barrier after its first write_act orders
         // both).  Without it a workgroup's 2nd+ tile ran its outermost halo rows on fp32 bit patterns read as 16-bit operands: the
@@ -411,7 +438,7 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
     int TTo = TT;
     if (p.wav) {   // fused conv_post (7 taps): the fp32 output tile may be larger than the activation tile it replaces
-        if (C != 32 || p.mode != 2 || !p.post_w || !p.post_b) return hipErrorInvalidValue;
+        if (C != 32 || (p.nrb == 1 && p.mode != 2) || !p.post_w || !p.post_b) return hipErrorInvalidValue;
         lds = std::max((size_t)TT * C * 4, (size_t)(W + 2 * RB_GUARD) * PITCH) + (size_t)WT * 32 * EP;
         TTo = TT - 6;
     }
@@ -461,6 +488,13 @@ bool rblock_supported(int C, int K) {
     return C == 32 || C == 64 || ((C == 128 || C == 256) && K == 3);
 }
 
+long long rblock_private_rows(int C, int Kmax, int B, int T) {
+    if (C != 32) return 0;
+    const int W = 1024, TT = W - 12 * (Kmax - 1), TTo = TT - 6;    // rb_launch_cfg<32, 4, 1, 8, 1, ., 1> with the fused conv_post
+    if (TTo < 32) return 0;
+    return (long long)B * ((T + TTo - 1) / TTo) * TT;
+}
+
 int rblock_padded_taps(int C, int K) {
     const int nkg = C / 16;
     int kp = K;
@@ -491,8 +525,14 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
         const int tt = W - 12 * (p.K - 1) - (p.wav ? 6 : 0);
         return small_ok && tt >= 32 && 2 * (long long)p.B * ((p.T + tt - 1) / tt) <= cus;
     };
-    // C = 32 without the fused conv_post: two phase-shifted groups per workgroup, a 512-row tile each (rblock2.hip)
-    if (!p.no_pingpong && rblock2_supported(C, p.K, p.wav != nullptr) && !few(512)) return rblock2_launch(p, C, stream);
+    if (p.nrb < 1 || p.nrb > 3) return hipErrorInvalidValue;
+    if (p.nrb > 1) {   // every ResBlock of the stage in one launch: the persistent full-size configurations only
+        if (C == 32) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
+        if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);
+        return hipErrorInvalidValue;
+    }
+    // (experiment, tune bit 7) C = 32 without the fused conv_post: two phase-shifted groups per workgroup (rblock2.hip)
+    if (p.pingpong && rblock2_supported(C, p.K, p.wav != nullptr) && !few(512)) return rblock2_launch(p, C, stream);
     if (C == 32 && rb32 && p.K >= 7 && !few(1024)) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
     if (C == 64 && few(512)) return rb_launch_cfg<64, 4, 1, 2, 2, EL, 1>(p, stream);     // 256-row tile, 4 waves
     if (C == 128 && few(256)) return rb_launch_cfg<128, 4, 1, 1, 4, EL, 1>(p, stream);   // 128-row tile, 4 waves

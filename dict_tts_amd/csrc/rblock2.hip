@@ -242,8 +242,8 @@ __global__ __launch_bounds__(128 * WT * WC, 1) void rblock2_kernel(const RBlockP
         uint4 ring[RD][NT];
         f32x4 bb[NT][4];
         RB2_T0();
-        rb2_preload<NT, RD>(ring, p.w1[0] + wlane, kg_stride);
-        load_bias(bb, p.b1[0]);
+        rb2_preload<NT, RD>(ring, p.rb[0].w1[0] + wlane, kg_stride);
+        load_bias(bb, p.rb[0].b1[0]);
         write_act(xr);
         RB2_T(0);
         __syncthreads();
@@ -274,10 +274,10 @@ __global__ __launch_bounds__(128 * WT * WC, 1) void rblock2_kernel(const RBlockP
                 for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cinit[n][4 * qq + e] = bb[n][qq][e];
-            load_bias(bb, p.b2[it]);
-            const int d = p.dil[it];
-            rb2_contract<EL, MT, NT, NKG, PITCH, RD, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.w1[it] + wlane, S, d * PITCH, cinit);
-            rb2_preload<NT, RD>(ring, p.w2[it] + wlane, kg_stride);
+            load_bias(bb, p.rb[0].b2[it]);
+            const int d = p.rb[0].dil[it];
+            rb2_contract<EL, MT, NT, NKG, PITCH, RD, true>(acc, ring, act, xlane - ((p.K - 1) / 2) * d * PITCH, p.rb[0].w1[it] + wlane, S, d * PITCH, cinit);
+            rb2_preload<NT, RD>(ring, p.rb[0].w2[it] + wlane, kg_stride);
             RB2_T(2);
             __syncthreads();
             RB2_T(3);
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(128 * WT * WC, 1) void rblock2_kernel(const RBlockP
                     for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) xr[m][n][4 * qq + e] += bb[n][qq][e];
-            if (it < 2) load_bias(bb, p.b1[it + 1]);
-            rb2_contract<EL, MT, NT, NKG, PITCH, RD, false>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.w2[it] + wlane, S, PITCH, cinit);
-            if (it < 2) rb2_preload<NT, RD>(ring, p.w1[it + 1] + wlane, kg_stride);
+            if (it < 2) load_bias(bb, p.rb[0].b1[it + 1]);
+            rb2_contract<EL, MT, NT, NKG, PITCH, RD, false>(xr, ring, act, xlane - ((p.K - 1) / 2) * PITCH, p.rb[0].w2[it] + wlane, S, PITCH, cinit);
+            if (it < 2) rb2_preload<NT, RD>(ring, p.rb[0].w1[it + 1] + wlane, kg_stride);
             if (p.tile_ctr && it == 0 && threadIdx.x == 0) pre[3 * p.B + 1] = G + (int)claim;
             if (it == 2) break;                    // (the barrier that closes the last contraction follows the loop)
             RB2_T(5);

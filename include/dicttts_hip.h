@@ -104,7 +104,8 @@ typedef struct dtts_config {
                                          13 two-product fp16 ups.1 (eats waveform margin), 16 strided g_pre_net, 17 fp32 MFMA instead of the
                                          three-piece bf16 products; LAYOUT: 6 raw (unprojected) dictionary table; SCHEDULE only: 0 conv_post as its
                                          own kernel, 1 upsamplers without the zero-tap skip, 2 static tile assignment, 3 no whole-ResBlock fusion
-                                         at C >= 128, 4 per-launch timer events, 5 128-row tiles for the narrow upsamplers.  (Builds made with
+                                         at C >= 128, 4 per-launch timer events, 5 128-row tiles for the narrow upsamplers, 7 two-group phase-shifted ResBlock kernel at
+                                         C = 32 (rblock2.hip), 9 all ResBlocks of a C <= 64 stage in one launch (less HBM traffic, not faster).  (Builds made with
                                          -DDTTS_ABLATE — `make ablate`, tools/ab_*.sh — additionally OR the DTTS_TUNE environment variable in and
                                          honour a few more schedule-only variables; the release library has no such code.) */
 } dtts_config;

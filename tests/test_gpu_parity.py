@@ -1264,3 +1264,25 @@ def test_memory_safety_other_kernel_families(voc_sd):
         if hp:
             _clean(f.ctx, "fft blocks")
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("flag,what", [(128, "two-group phase-shifted C = 32 ResBlock kernel (rblock2.hip)"),
+                                       (512, "all ResBlocks of a C <= 64 stage in one launch, private stage-sum strips under the fused conv_post")])
+def test_optin_resblock_forms_are_bit_identical_to_the_default(voc_sd, voc_plain, flag, what):
+    """round 4's two measured-and-not-adopted ResBlock forms (dtts_config.tune_flags bits 7 and 9; LABNOTES round 4) compute the SAME bits
+    as the default launches — 70 ragged utterances (several tiles per persistent workgroup, odd tile counts, empty rows) and a B = 24 batch
+    large enough for the stage-fused form to engage — and stay clean under the memory-safety mode"""
+    from dict_tts_amd import vocoder
+    v = vocoder.HifiGAN(state_dict=voc_sd, config={**synth.hifigan_config(), "dtts_tune_flags": flag, "dtts_debug_redzone": 1}, precision="f16")
+    rng = np.random.RandomState(11)
+    for lens, Tm in (([0, 1, 61, 2, 33] + [int(x) for x in rng.randint(0, 62, size=65)], 64), ([int(x) for x in rng.randint(200, 701, size=23)] + [700], 700)):
+        B = len(lens)
+        mel = np.zeros((B, Tm, 80), np.float32)
+        for i, n in enumerate(lens):
+            if n:
+                mel[i, :n] = synth.random_mel(500 + i, n, f"opt{i}")
+        lens_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        got = v.forward_batch(T(mel).cuda(), lens_d).cpu().numpy()
+        _clean(v.ctx, what)
+        want = voc_plain.forward_batch(T(mel).cuda(), lens_d).cpu().numpy()
+        assert np.isfinite(got).all() and np.array_equal(got, want), what
