@@ -242,4 +242,68 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&
     }
 }
 
+// ---- contraction over the REAL k-steps with a weight ring of RD register sets (fragments RD - 1 steps ahead; the activation fragments one
+// step ahead).  rblock2.hip (one wave per SIMD in a matrix phase: a step takes 32 * MT * NT cycles, rb_contract's 3-step prefetch would
+// expose the L2 round trip) uses RD = 8; rblock.hip's C = 32 configurations use RD = 4 for the second property:  Steps are the REAL k-steps K * NKG (the zero
+// padding of the packs to a multiple of four steps is not computed): the loop is unrolled over RD steps with a uniform exit at every tap
+// boundary.  The packs carry >= 8 k-steps of slack and the LDS tile a spare tap of guard rows, so the prefetches past the end need no clamps.
+template <int NT, int RD>
+__device__ __forceinline__ void rb2_preload(uint4 (&ring)[RD][NT], const uint4* w, int kgs) {
+#pragma unroll
+    for (int s = 0; s < RD - 1; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kgs + n * 64];
+}
+
+template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool FIRST, bool CINIT>
+__device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[RD][NT], uint4 (&xa)[2][MT],
+                                          const char* act, const uint4* wpf, int xb, int dilP, int left) {   // left: steps still to do (> 0)
+    constexpr int KGS = (NKG / 2) * 64;
+    static_assert(RD % NKG == 0 && RD % 2 == 0, "a ring turn covers whole taps");
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+        if (u && u % NKG == 0 && u >= left) return true;                // (uniform) the last tap is done
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ring[(u + RD - 1) % RD][n] = wpf[u * KGS + n * 64];
+        {
+            const int off = xb + ((u + 1) / NKG) * dilP + ((u + 1) % NKG) * 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (FIRST && CINIT) {
+                    if (u == 0) {
+                        acc[m][n] = mfma16<EL>(ring[u][n], xa[u & 1][m], cinit[n]);
+                        continue;
+                    }
+                }
+                acc[m][n] = mfma16<EL>(ring[u][n], xa[u & 1][m], acc[m][n]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return left <= RD;
+}
+
+// acc (+)= W * act over the S = K * NKG real steps; ring holds steps 0 .. RD - 2 on entry (rb2_preload).  CINIT: acc = cinit + W * act.
+template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool CINIT>
+__device__ __forceinline__ void rb2_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[RD][NT], const char* act, int xrow0, const uint4* w, int S,
+                                             int dilP, const f32x16 (&cinit)[NT]) {
+    constexpr int KGS = (NKG / 2) * 64;
+    uint4 xa[2][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
+    const uint4* wpf = w + (RD - 1) * KGS;
+    int xb = xrow0;
+    if (rb2_group<EL, MT, NT, NKG, PITCH, RD, true, CINIT>(acc, cinit, ring, xa, act, wpf, xb, dilP, S)) return;
+    for (int left = S - RD;; left -= RD) {
+        wpf += RD * KGS;
+        xb += (RD / NKG) * dilP;
+        if (rb2_group<EL, MT, NT, NKG, PITCH, RD, false, CINIT>(acc, cinit, ring, xa, act, wpf, xb, dilP, left)) return;
+    }
+}
+
 } // namespace dtts

@@ -173,13 +173,17 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }
     const int xlane = (RB_GUARD + wt * MT * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
     const size_t wlane = (size_t)(wc * NT) * 64 + lane;
-    r = __builtin_amdgcn_readfirstlane(r);
-    const RBlockParams::Set& R = p.rb[r];
+    if constexpr (PS) r = __builtin_amdgcn_readfirstlane(r);
+    else r = 0;                                      // (one tile per workgroup: one ResBlock per launch)
+    const RBlockParams::Set& R = p.rb[PS ? r : 0];
     const int Kr = R.K;                              // this ResBlock's kernel size (the tile's halo follows the launch's largest)
-    const int S = DTTS_DBG(p, 1) ? 0 : R.Kp * NKG;   // packed taps (zero padded so that S % 4 == 0)
-    const bool last_rb = r + 1 == p.nrb;
+    // C = 32 (two k-groups per tap): the packs' zero padding to a multiple of four steps would be 25 / 12.5 / 8 % of the MFMAs at k = 3 / 7 / 11:
+    // those configurations run the real steps only (rb2_contract, uniform exit at tap boundaries)
+    constexpr bool REAL_STEPS = (NKG < 4);
+    const int S = DTTS_DBG(p, 1) ? 0 : (REAL_STEPS ? Kr : R.Kp) * NKG;   // k-steps (packed taps are zero padded so that Kp * NKG % 4 == 0)
+    const bool last_rb = !PS || r + 1 == p.nrb;
     // what the epilogue does with the stage sum: one ResBlock per launch: p.mode; all of the stage's: write, accumulate.., finish
-    const int mode = p.nrb == 1 ? p.mode : (r == 0 ? 0 : (last_rb ? 2 : 1));
+    const int mode = (!PS || p.nrb == 1) ? p.mode : (r == 0 ? 0 : (last_rb ? 2 : 1));
     const bool wav_now = p.wav && last_rb;
     t0 = __builtin_amdgcn_readfirstlane(t0);
     const int base_t = t0 - H;  // global time of local row 0
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
         load_bias(bb, R.b2[it]);       // lands while conv1 runs
         const int d = R.dil[it];
-        rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
+        if constexpr (REAL_STEPS) {
+            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, cinit);
+            else rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, 0, R.w1[it] + wlane, 0, 0, kg_stride, &cinit);
+        } else
+            rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, R.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         __syncthreads();               // every wave is done reading A
         write_act(acc);                // xt (bf16, activated) overwrites it
@@ -290,7 +298,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
         if (it < 2) load_bias(bb, R.b1[it + 1]);
-        rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
+        if constexpr (REAL_STEPS) {
+            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, false>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, cinit);
+        } else
+            rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, R.w1[it + 1] + wlane, kg_stride);
         if (PS && p.tile_ctr && last_rb && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
         __syncthreads();               // every wave is done reading xt
