@@ -73,7 +73,7 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
       thread sweep: rows 0..5 x 2 passes at {8, 16, 32, 64, physical cores} torch threads (those that the box has); the best count runs the
                     protocol and is stated as `cores`, all three rates are listed (a B=1 forward does not scale to 128 threads);
       mode 'protocol' (default): all 60 rows, up to 5 repetitions inside a time budget (`budget_s`, at least one full repetition;
-                    the number completed is stated), batched variant B=8 (one pass);
+                    the number completed is stated), batched variant B=60 (one pass at the best thread count of a B=8 sweep);
       mode 'full':  no budget, 5 repetitions, batched variant B=60 (3 timed passes after a warm-up);
       mode 'bounded': rows 0..2 x 5 repetitions, batched B=4 (round 2's default, ~35 s).
     The same leg checks the GPU vocoder against the oracle waveform on the first utterance's ORACLE mel (this is the only place
@@ -89,7 +89,7 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
     cfg = synth.hifigan_config()
     st = synth.biaobei_struct()
     n_utt = 3 if mode == "bounded" else 60
-    n_batched = {"bounded": 4, "protocol": 8, "full": 60}[mode]
+    n_batched = {"bounded": 4, "protocol": 60, "full": 60}[mode]
     rms = lambda a: float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64)))))
     inputs = {}
 
@@ -141,21 +141,35 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
     n_reps = len(reps)
     reps.sort()
     e2e, t2m, vocr, frames = reps[len(reps) // 2]
-    # batched variant: the first n_batched rows as one batch (text->mel) + one batched generator call on the padded mel
-    bb = {k: T(v) for k, v in synth.make_batch(st["sentences"][:n_batched], 1234).items()}
+    # batched variant: the first n_batched rows as ONE batch (text->mel) + one batched generator call on the padded mel.
+    # A B = 60 forward scales to more threads than a B = 1 one: its thread count is the best of {B=1's best, 32, 64, physical} measured on a
+    # B = 8 batch (listed), then the full batch runs once at that count (mode 'full': 3 timed passes after a warm-up).
+    def batched_pass(nb, zb_):
+        bb_ = batched_inputs[nb]
+        t0 = time.perf_counter()
+        r = ref.forward_infer(sd, bb_["word_tokens"], (bb_["keys"], bb_["values"], bb_["key_map"], bb_["pinyin"], bb_["pinyin_map"]),
+                              bb_["pron_modified"], z_p=lambda B, T4: zb_[:B, :, :T4])
+        with torch.no_grad():
+            href.generator_forward(hsd, cfg, r["mel_out"].transpose(1, 2).contiguous())
+        return int((r["mel2word"] > 0).sum()) / (time.perf_counter() - t0)
+
     zb = T(synth.noise(1234, n_batched, 1024, "cpu.zb"))
+    batched_inputs = {nb: {k: T(v) for k, v in synth.make_batch(st["sentences"][:nb], 1234).items()} for nb in sorted({min(8, n_batched), n_batched})}
+    b_sweep = {}
+    b_threads = threads
+    if mode != "bounded":
+        for th in sorted({t for t in (threads, 32, 64, phys) if 1 <= t <= max(1, logical)}):
+            torch.set_num_threads(th)
+            b_sweep[str(th)] = batched_pass(min(8, n_batched), zb)
+        b_threads = int(max(b_sweep, key=lambda k: b_sweep[k]))
+    torch.set_num_threads(b_threads)
     bt = []
     for rep in range(4 if mode == "full" else 1):          # full: the first pass is a warm-up; otherwise one pass, the threads are warm
-        t0 = time.perf_counter()
-        r = ref.forward_infer(sd, bb["word_tokens"], (bb["keys"], bb["values"], bb["key_map"], bb["pinyin"], bb["pinyin_map"]),
-                              bb["pron_modified"], z_p=lambda B, T4: zb[:, :, :T4])
-        with torch.no_grad():
-            wb = href.generator_forward(hsd, cfg, r["mel_out"].transpose(1, 2).contiguous())
-        dt = time.perf_counter() - t0
-        fb = int((r["mel2word"] > 0).sum())
+        v = batched_pass(n_batched, zb)
         if rep or mode != "full":
-            bt.append(fb / dt)
+            bt.append(v)
     bt.sort()
+    torch.set_num_threads(threads)
     out = {"value": e2e, "unit": "mel-frames/s", "cores": threads, "kind": "port",
            "cpu_model": model_name, "physical_cores": phys, "logical_cpus": logical,
            "thread_sweep_mel_frames_per_s": sweep,
@@ -166,7 +180,8 @@ def cpu_baseline(torch, np, synth, voc, mode="protocol", budget_s=420.0):
                      + (f", time budget {budget_s:.0f} s" if mode == "protocol" else ""),
            "repetitions": n_reps,
            "text2mel_frames_per_s": t2m, "vocoder_frames_per_s": vocr, "samples_per_s": e2e * 256, "rtf": 22050.0 / (e2e * 256),
-           "batched": {"value": bt[len(bt) // 2], "unit": "valid mel-frames/s", "B": n_batched,
+           "batched": {"value": bt[len(bt) // 2], "unit": "valid mel-frames/s", "B": n_batched, "cores": b_threads,
+                       "thread_sweep_on_B8_mel_frames_per_s": b_sweep,
                        "note": "one forward_infer + one generator call on the padded batch (padding frames are computed, not counted)"},
            "cpu_seconds": time.perf_counter() - t_start}
     if voc is not None:   # waveform gates of the benched vocoder mode, measured on this box
@@ -253,6 +268,9 @@ def main():
         except Exception:
             uuid = ""
         seen = ranks_seen(dist, device_index=local_rank, device_uuid=uuid)
+        assert seen is not None and len(seen) == world and sorted(r["rank"] for r in seen) == list(range(world)), seen
+        if not one_dev:   # a real multi-GPU run: the collective backend must have seen `world` DISTINCT devices
+            assert len({(r["device_index"], r["device_uuid"]) for r in seen}) == world, f"ranks share a device: {seen}"
 
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     # ---- weights (random-init of the real architecture) and the acoustic model / vocoder behind the reference APIs
@@ -507,15 +525,41 @@ def main():
             # (hidden_size = 192 floats each): 2 x 768 B per live gloss row (include/dicttts_hip.h: dtts_dict_table_upload)
             row_bytes = 2 * 4 * 192
             gbs = row_bytes * hb["live_gloss_rows"] / (s2pa_ms / max(s2pa_n, 1) * 1e-3) / 1e9
-            stages["s2pa_roofline"] = {"bound": "hbm (nominal) - the kernel is LATENCY-bound: ~15 live rows per word, one dependent chain "
-                                                "entry -> offsets -> key_map -> rows -> reductions per workgroup (DESIGN.md 3.3)",
+            stages["s2pa_roofline"] = {"bound": f"hbm (nominal) - the kernel is LATENCY-bound: {s2pa_ms / max(s2pa_n, 1) * 1e3:.1f} us per launch, ~15 live rows per word, "
+                                                "one dependent chain entry -> offsets -> key_map -> rows -> reductions per workgroup (DESIGN.md 3.3)",
                                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                        "kernel": "dtts::s2pa_kernel<1, 8> (resident table of PRE-PROJECTED rows, gathered by entry id)",
-                                       "avg_launch_ms": s2pa_ms / max(s2pa_n, 1),
+                                       "avg_launch_ms": s2pa_ms / max(s2pa_n, 1), "avg_launch_us": s2pa_ms / max(s2pa_n, 1) * 1e3,
                                        "algorithmic_bytes": f"{row_bytes} B x live gloss rows of the batch's entries (fp32 K + V, 192 wide each; "
                                                             "the tensor API reads 6144 B per row: raw 768-wide key + value)",
                                        "bytes_per_launch": row_bytes * hb["live_gloss_rows"],
                                        "live_gloss_rows": hb["live_gloss_rows"]}
+        # BASELINE.md §4 row "S2PA (A3), tensor API": the drop-in API's own kernel (s2pa_kernel<3, .>: raw 768-wide key + value rows of the
+        # collated tensors, re-associated logits key . (Wk^T q)) on tensors ALREADY RESIDENT in HBM (the PCIe-inclusive figure is side.tensor_api_incl_h2d)
+        tb0 = {k: T(v).to(dev) for k, v in synth.make_batch(hb["sent"], 1234).items()}
+        live_t = int((tb0["key_map"] != 0).sum().item())
+        m.ctx.timer_reset()
+        for _ in range(4):
+            m.ctx.text2mel_encode(ptr(tb0["word_tokens"]), ptr(tb0["keys"]), ptr(tb0["values"]), ptr(tb0["key_map"]), ptr(tb0["pinyin"]),
+                                  ptr(tb0["pinyin_map"]), ptr(tb0["pron_modified"]), None, hb["B"], hb["T_w"], tb0["keys"].shape[2],
+                                  tb0["pinyin"].shape[2], stream)
+        torch.cuda.synchronize()
+        s2t_ms, s2t_n = m.ctx.timer_read(abi.TIMER_S2PA)
+        if s2t_ms > 0:
+            per = s2t_ms / max(s2t_n, 1)
+            gbs_t = 6144.0 * live_t / (per * 1e-3) / 1e9
+            stages["s2pa_tensor_roofline"] = {
+                "bound": "hbm (nominal)" + ("" if gbs_t / PEAK_HBM_GBS >= 0.5 else f" - LATENCY-bound: {per * 1e3:.1f} us per launch, one dependent chain key_map -> live-row list -> "
+                                                                                   "rows -> reductions per word and ~15 live rows of 6 KB per word (DESIGN.md 3.3)"),
+                "achieved": gbs_t, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs_t / PEAK_HBM_GBS,
+                "kernel": "dtts::s2pa_kernel<3, .> (tensor API: collated keys / values [B,T_w,L_k,768] resident in HBM)",
+                "avg_launch_ms": per, "avg_launch_us": per * 1e3, "launches": s2t_n,
+                "algorithmic_bytes": "6,144 B (fp32 key row + value row, 768 wide each) x live gloss rows (key_map != 0) of the batch (BASELINE.md §4)",
+                "bytes_per_launch": 6144 * live_t, "live_gloss_rows": live_t,
+                "padded_bytes_per_launch": int(6144 * hb["B"] * hb["T_w"] * tb0["keys"].shape[2]),
+                "note": "the padded tensors hold 6,144 x B x T_w x L_k bytes; the kernel reads only the live rows"}
+        del tb0
+        m.ctx.text2mel_encode_ids(ptr(d["word_tokens"]), ptr(d["entry_ids"]), ptr(d["pron_modified"]), None, hb["B"], hb["T_w"], hb["L_k"], hb["P"], stream)   # (back on the table path)
         # A2 (BASELINE.md §4 row "Text encoder blocks, fp32 MFMA, 157.3 TF"): SURVEY 8d counts 8 * (2,064,384 + 768 T_w) FLOP per word
         # token for the two 4-layer encoders; time = the 'dict_encoder' span (embedding + both encoders + S2PA: slightly conservative)
         a2_flop = 8.0 * (2_064_384 + 768 * hb["T_w"]) * hb["B"] * hb["T_w"]

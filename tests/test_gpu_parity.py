@@ -1286,3 +1286,49 @@ def test_optin_resblock_forms_are_bit_identical_to_the_default(voc_sd, voc_plain
         _clean(v.ctx, what)
         want = voc_plain.forward_batch(T(mel).cuda(), lens_d).cpu().numpy()
         assert np.isfinite(got).all() and np.array_equal(got, want), what
+
+
+def test_rccl_world1_gather_mels_and_ranks_seen_on_the_gpu():
+    """the CUDA-tensor path of the data-parallel helpers through RCCL itself (backend 'nccl' on ROCm), which the world-2
+    gloo tests on the CPU cannot reach: a world-size-1 nccl group on the one GPU, `gather_mels(None, None)` (a rank without a batch),
+    `gather_mels(mel, lens)` with device tensors, `ranks_seen`, and the frame all-reduce bench.py does.  Runs in a child process (the process
+    group is process-global)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, socket, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from dict_tts_amd.shard import gather_mels, ranks_seen, group_device
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+assert group_device(dist) == dev
+seen = ranks_seen(dist, device_index=0, device_uuid=str(torch.cuda.get_device_properties(dev).uuid))
+assert len(seen) == 1 and seen[0]["rank"] == 0 and seen[0]["device_index"] == 0 and seen[0]["device_uuid"]
+m0, l0, meta0 = gather_mels(None, None, dist)
+assert m0 is None and l0 is None and meta0.tolist() == [[0, 0]]
+g = torch.Generator(device="cpu").manual_seed(3)
+mel = torch.randn(5, 37, 80, generator=g).to(dev)
+lens = torch.tensor([37, 20, 1, 0, 36], dtype=torch.int32, device=dev)
+side = torch.cuda.Stream(device=dev)
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):                       # bench.py gathers on a side stream
+    ma, la, meta = gather_mels(mel, lens, dist)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+assert ma.is_cuda and ma.shape == (1, 5, 37, 80) and torch.equal(ma[0], mel) and torch.equal(la[0], lens) and meta.tolist() == [[5, 37]]
+f = torch.tensor([12345], dtype=torch.int64, device=dev)
+dist.all_reduce(f)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert int(f.item()) == 12345 and float(t.item()) == 1.5
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"ok": True, "seen": seen}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"ok": true' in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

@@ -40,7 +40,11 @@ S="$B --no-pipeline --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_fetch -o p -- $S > $OUT/pmc_fetch_bench.json 2> /tmp/pr_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_write -o p -- $S > $OUT/pmc_write_bench.json 2> /tmp/pr_write.err
 read N F <<< $(python -c "import json; d=json.load(open('$OUT/pmc_fetch_bench.json'))['config']['all_forwards']; print(d['n'], d['mel_frames'])")
-python $R/tools/pmc_traffic.py $(find /tmp/pr_fetch -name "*.db" | head -1) $(find /tmp/pr_write -name "*.db" | head -1) $N $F f16 > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
+# both S2PA paths on resident tensors (tensor API kernel s2pa_kernel<3,.> and the table kernel), same two counters
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_s2f -o p -- python $R/tools/s2pa_probe.py > $OUT/s2pa_probe.json 2> /tmp/pr_s2f.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_s2w -o p -- python $R/tools/s2pa_probe.py > /dev/null 2> /tmp/pr_s2w.err
+python $R/tools/pmc_traffic.py $(find /tmp/pr_fetch -name "*.db" | head -1) $(find /tmp/pr_write -name "*.db" | head -1) $N $F f16 \
+    $(find /tmp/pr_s2f -name "*.db" | head -1) $(find /tmp/pr_s2w -name "*.db" | head -1) $OUT/s2pa_probe.json > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
 cd $R
 bash tools/prof_pmc.sh ${TAG}_u dtts:: -- $S > /dev/null 2>&1
 mv $R/gpurun_out/${TAG}_u_pmc_util.md $OUT/pmc_util.md 2>/dev/null
