@@ -259,8 +259,12 @@ extern "C" int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMe
 #else
 #define STAMP(i)
 #endif
-template <int ENGINE, int NT, int WC, int KS, int U>
-__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1 : 2) : 3) void conv1d_short_kernel(const ConvParams p) {
+// PP: contraction PARTS per wave.  The contraction of an output tile is always summed as P = KS * PP partial sums — part j = the k-groups
+// [j NG / P, (j + 1) NG / P) of every tap, combined ((p0 + p1) + p2) + p3 — where P depends on the LAYER only (4 if its k-group count
+// divides by 4, else 2, else 1): how many waves share the parts (KS = 4 / 2 / 1, chosen per launch from the grid size and the CU count)
+// does not change a single bit of the result, so an utterance gets the same log-durations alone and inside any batch.
+template <int ENGINE, int NT, int WC, int KS, int U, int PP>
+__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1 : 2) : (PP > 1 && ENGINE == ENG_BF16X6 ? 2 : 3)) void conv1d_short_kernel(const ConvParams p) {
     constexpr int MT = 1, WT = 1;   // one 32-row time tile per workgroup
     static_assert(WC * KS == 4, "four waves: co-tile groups x contraction splits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,13 +296,16 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
     const int pitch = p.C_in_pad * ES + 16;   // +16 B: conflict-free ds_read_b128 across 16 rows ((C_in_pad * ES + 16) mod 256 == 16 for the widths in use)
     const int plane = rows * pitch;   // bytes between the planes of the staged tile
 
-    f32x16 acc[MT][NT];
+    f32x16 accp[PP][MT][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[pp][m][n][r] = 0.f;
+    f32x16 (&acc)[MT][NT] = accp[0];   // the combined sum ends up in part 0's registers
 
     const float* xb = p.x + (long long)b * p.x_bstride + p.x_coff;
     const bool live = t0 < out_len;
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
     // one step's MFMAs: weight fragments bw[plane][n] x activation fragments aw[plane][m] into every (m, n) accumulator.  Split
     // operands: every product of pieces i, j with i + j < NP, smallest first (x3: 3 products ~ 2^-16; x6: 6 products ~ 2^-24, the
     // fp32 MFMA's accuracy at 6 x 8 passes per 16 channels instead of 8 x 16)
-    auto mma = [&](const uint4 (&bw)[NP][NT], const uint4 (&aw)[NP][MT]) {
+    auto mma = [&](f32x16 (&acc)[MT][NT], const uint4 (&bw)[NP][NT], const uint4 (&aw)[NP][MT]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -438,15 +445,18 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
     // meet in LDS in a fixed order (ks = 0 + 1 + 2 + 3).
     if (live) {
         constexpr int R = 4, PF = 3;
-        const int NGW = NG / KS;                      // k-groups per tap and wave (the launcher checks NG % KS == 0)
+        const int NGW = NG / (KS * PP);               // k-groups per tap and PART (the launcher checks NG % (KS * PP) == 0)
         const int S = p.K * NGW;
         const int kg_stride_i = NCT * 64, tap_wrap_w = (NG - NGW) * NCT * 64;
-        const uint4* wp[3] = {(const uint4*)p.w_hi + (size_t)ks * NGW * NCT * 64 + lane, (const uint4*)p.w_lo + (size_t)ks * NGW * NCT * 64 + lane,
-                              (const uint4*)p.w_lo2 + (size_t)ks * NGW * NCT * 64 + lane};
         int ctc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) ctc[n] = ct0 + n < NCT ? ct0 + n : NCT - 1;
-        // two cursors over the wave's step sequence (weights run PF steps ahead, activations one), advanced by adds; both stop on
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+        const int part = ks * PP + pp;                // this wave's parts: ks * PP .. ks * PP + PP - 1
+        const uint4* wp[3] = {(const uint4*)p.w_hi + (size_t)part * NGW * NCT * 64 + lane, (const uint4*)p.w_lo + (size_t)part * NGW * NCT * 64 + lane,
+                              (const uint4*)p.w_lo2 + (size_t)part * NGW * NCT * 64 + lane};
+        // two cursors over the part's step sequence (weights run PF steps ahead, activations one), advanced by adds; both stop on
         // the last step
         int wo = 0, wg = 0, ws = 0;
         auto load_w = [&](uint4 (&d)[NP][NT]) {
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
                 }
             }
         };
-        const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + ks * NGW * KG * ES;
+        const int abase = ((wt * MT) * 32 + (lane & 31)) * p.stride * pitch + (lane >> 5) * (KG / 2) * ES + part * NGW * KG * ES;
         const int tap_wrap_x = p.dil * pitch - NGW * KG * ES;
         int xo = 0, xg = 0, xs = 0;
         auto load_x = [&](uint4 (&d)[NP][MT]) {
@@ -490,34 +500,50 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
                 load_w(rw[(j + PF) % R]);
                 load_x(xa[(j + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s + j < S) mma(rw[j], xa[j & 1]);
+                if (s + j < S) mma(accp[pp], rw[j], xa[j & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (KS > 1) {
-            __syncthreads();   // every wave is done with the staged rows: their LDS takes the partial sums
-            float* red = (float*)smem;
-            const int tile = wave % (WT * WC);
-            if (ks > 0) {
+        }   // (parts of this wave)
+        // ---- combine the P = KS * PP partial sums in the fixed order ((p0 + p1) + p2) + p3: this wave's own parts first ...
+        if (KS == 1 || ks == 0) {
+#pragma unroll
+            for (int pp = 1; pp < PP; ++pp)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            red[(((((ks - 1) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane] = acc[m][n][r];
-            }
-            __syncthreads();
-            if (ks == 0) {
+                        for (int r = 0; r < 16; ++r) accp[0][m][n][r] += accp[pp][m][n][r];
+        }
+        if constexpr (KS > 1) {   // ... then the other waves' parts, one by one, through LDS
+            __syncthreads();   // every wave is done with the staged rows: their LDS takes the partial sums
+            float* red = (float*)smem;
+            const int tile = wave % (WT * WC);
+            if (ks > 0) {
 #pragma unroll
-                for (int k2 = 1; k2 < KS; ++k2)
+                for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                acc[m][n][r] += red[(((((k2 - 1) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane];
+                                red[((((((ks - 1) * PP + pp) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane] = accp[pp][m][n][r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+                    for (int pp = 0; pp < PP; ++pp)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    acc[m][n][r] += red[((((((k2 - 1) * PP + pp) * (WT * WC) + tile) * MT + m) * NT + n) * 16 + r) * 64 + lane];
             }
         }
     }
@@ -643,12 +669,12 @@ static int cu_count() {
     return n_cu;
 }
 
-template <int ENGINE, int NT, int WC, int KS, int U>
+template <int ENGINE, int NT, int WC, int KS, int U, int PP>
 static hipError_t launch_short_u(const ConvParams& p, hipStream_t stream) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2;
     constexpr size_t LDS_CU = 160 * 1024;
-    const size_t lds = short_lds(p, ES, ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1, (KS - 1) * WC * NT);
-    auto kern = conv1d_short_kernel<ENGINE, NT, WC, KS, U>;
+    const size_t lds = short_lds(p, ES, ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1, (KS - 1) * PP * WC * NT);
+    auto kern = conv1d_short_kernel<ENGINE, NT, WC, KS, U, PP>;
     static bool configured_dev[64] = {};   // per device: hipFuncSetAttribute is per device
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
@@ -662,12 +688,12 @@ static hipError_t launch_short_u(const ConvParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int ENGINE, int NT, int WC, int KS>
+template <int ENGINE, int NT, int WC, int KS, int PP = 1>
 static hipError_t launch_short(const ConvParams& p, hipStream_t stream) {
     // 16 B pieces of the staged tile per thread: 8 in flight at 4 workgroups per CU (<= 128 VGPRs), or 24 for the wide tiles (LDS
     // leaves one workgroup per CU anyway)
     const size_t pieces = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4);
-    return pieces <= 256 * 8 ? launch_short_u<ENGINE, NT, WC, KS, 8>(p, stream) : launch_short_u<ENGINE, NT, WC, KS, 24>(p, stream);
+    return pieces <= 256 * 8 ? launch_short_u<ENGINE, NT, WC, KS, 8, PP>(p, stream) : launch_short_u<ENGINE, NT, WC, KS, 24, PP>(p, stream);
 }
 
 // Few rows (the T_w ~ 27 encoder at B = 60, one long text at B = 1: <= 256 tiles of 32 rows): bound by the serial MFMA chain of one wave
@@ -677,30 +703,41 @@ template <int ENGINE>
 static bool launch_short_policy(const ConvParams& p, hipStream_t stream, hipError_t* err) {
     constexpr int ES = (ENGINE == ENG_F32) ? 4 : 2, KG = (ENGINE == ENG_F32) ? 8 : 16, NP = ENGINE == ENG_BF16X6 ? 3 : ENGINE == ENG_BF16X3 ? 2 : 1;
     const size_t lds = short_lds(p, ES, NP, 0);
-    if ((long long)p.B * ((p.T_out + 31) / 32) > 256 || lds > 150 * 1024) return false;
+    // the three-piece engine IS the layer's arithmetic (fixed when the weights were packed): it takes every problem size whose 32-row
+    // tile fits the LDS; the exact-fp32 MFMA engine keeps the few-rows limit (beyond it the generic kernel computes the same products)
+    if (lds > 150 * 1024 || (ENGINE != ENG_BF16X6 && (long long)p.B * ((p.T_out + 31) / 32) > 256)) return false;
     if (p.gate_H) {
         *err = launch_short<ENGINE, 2, 4, 1>(p, stream);                           // 32 t x 256 co
         return true;
     }
-    // split the contraction over the workgroup's waves (each output tile's chain 2x / 4x shorter, 2x / 4x the workgroups) as far
-    // as ALL workgroups stay co-resident: a second round of workgroups costs more than the shorter chains give
+    // The contraction is summed in P parts fixed by the LAYER (see the kernel); the parts are spread over 4 / 2 / 1 waves (each output
+    // tile's chain 4x / 2x shorter, 4x / 2x the workgroups) as far as ALL workgroups stay co-resident: a second round of workgroups
+    // costs more than the shorter chains give.  That choice depends on the grid and the device — the result does not.
     static const int ks_env = [] { const char* e = ablate_env("DTTS_C1D_KS"); return e ? atoi(e) : 0; }();   // A/B override
     const int n_cu = cu_count();
     const int NG = p.C_in_pad / KG;
+    const int P = NG % 4 == 0 ? 4 : (NG % 2 == 0 ? 2 : 1);
     const size_t per_cu_lds = (160 * 1024) / lds;
     const bool wide = ((size_t)31 * p.stride + (size_t)(p.K - 1) * p.dil + 1) * (p.C_in_pad / 4) > 256 * 8;
     const size_t tiles = (size_t)((p.T_out + 31) / 32) * p.B;
     int ks = 1;
-    for (int k = 4; k >= 2 && ks == 1; k >>= 1) {
-        if (NG % k) continue;
-        const size_t occ = wide ? 2 : (k == 4 ? 3 : (ENGINE == ENG_F32 ? 4 : 3));   // waves per SIMD the kernel's registers allow
+    for (int k = P; k >= 2 && ks == 1; k >>= 1) {
+        // waves per SIMD the kernel's registers allow (k < P: the wave carries P / k accumulator sets)
+        const size_t occ = wide ? 2 : (k == P ? (k == 4 ? 3 : (ENGINE == ENG_F32 ? 4 : 3)) : (ENGINE == ENG_F32 ? 3 : 2));
         const size_t wgs = tiles * ((p.C_out_pad + 32 * (4 / k) - 1) / (32 * (4 / k)));
         if (wgs <= (size_t)n_cu * (occ < per_cu_lds ? occ : per_cu_lds)) ks = k;
     }
-    if (ks_env == 1 || ks_env == 2 || ks_env == 4) ks = (NG % ks_env == 0) ? ks_env : 1;
-    if (ks == 4) *err = launch_short<ENGINE, 1, 1, 4>(p, stream);         // 32 t x 32 co, contraction in 4
-    else if (ks == 2) *err = launch_short<ENGINE, 1, 2, 2>(p, stream);    // 32 t x 64 co, contraction in 2
-    else *err = launch_short<ENGINE, 1, 4, 1>(p, stream);                 // 32 t x 128 co
+    if ((ks_env == 1 || ks_env == 2 || ks_env == 4) && P % ks_env == 0) ks = ks_env;
+    if (P == 4) {
+        if (ks == 4) *err = launch_short<ENGINE, 1, 1, 4, 1>(p, stream);         // 32 t x 32 co, one part per wave
+        else if (ks == 2) *err = launch_short<ENGINE, 1, 2, 2, 2>(p, stream);    // 32 t x 64 co, two parts per wave
+        else *err = launch_short<ENGINE, 1, 4, 1, 4>(p, stream);                 // 32 t x 128 co, all four parts in one wave
+    } else if (P == 2) {
+        if (ks == 2) *err = launch_short<ENGINE, 1, 2, 2, 1>(p, stream);
+        else *err = launch_short<ENGINE, 1, 4, 1, 2>(p, stream);
+    } else {
+        *err = launch_short<ENGINE, 1, 4, 1, 1>(p, stream);
+    }
     return true;
 }
 

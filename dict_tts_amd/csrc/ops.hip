@@ -483,9 +483,11 @@ __global__ __launch_bounds__(256) void mha_mfma_split_kernel(const float* qkv, f
 hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int T, int C, int heads, hipStream_t s) {
     const int dk = C / heads;
     if (dk == MHX_DK) {
-        // few long sequences: keys split over the waves (see mha_mfma_split_kernel) while the 128-query form would fill < half the CUs
+        // long sequences (T > 128): keys split over the waves (see mha_mfma_split_kernel; built for few long sequences, where the
+        // 128-query form fills < half the CUs).  The rule depends on T ONLY — not on B or the device — because the two kernels merge their
+        // partial softmax sums in different orders: an utterance must get the same encoder output alone and inside any batch
         static const bool split_ok = [] { const char* e = ablate_env("DTTS_MHA_SPLIT"); return !e || atoi(e) != 0; }();
-        if (split_ok && T > 128 && (long long)((T + 127) / 128) * heads * B <= 128) {
+        if (split_ok && T > 128) {
             constexpr int LDS = 8 * MHX_KT * MHX_PITCH + 8 * 32 * (int)sizeof(float);
             static bool configured_dev[64] = {};
             int cur_dev = 0;

@@ -1332,3 +1332,26 @@ print(json.dumps({"ok": True, "seen": seen}))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and '"ok": true' in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_results_do_not_depend_on_batch_composition(acoustic):
+    """the arithmetic of every layer is fixed when its weights are packed — the contraction of a short-sequence
+    convolution is always summed in the same P parts in the same order however many waves share them (conv1d.hip), the attention kernel is
+    chosen from T alone — so an utterance gets BIT-identical log-durations, encoder output, dictionary attention and (with the same z_p)
+    mel whether it runs alone (B = 1: contraction over 4 waves) or as row u of a B = 60 batch (over 2 or 1).  Utterances are padded to the
+    batch's T_w / L_k for the comparison's inputs only (the reference pads the same way, dataset_utils.py:264-330)."""
+    st = synth.biaobei_struct()
+    sents = st["sentences"][:60]
+    full = synth.make_batch(sents, gc.SEED)
+    r60 = _run(acoustic, full)
+    lens60 = (full["word_tokens"] > 0).sum(1)
+    for u in (0, 7, 31, 59):
+        one = {k: v[u:u + 1] for k, v in full.items()}           # the same padded row, alone
+        r1 = _run(acoustic, one)
+        n = int(lens60[u])
+        for k in ("dur", "word_encoder_out", "pron_attn"):
+            a, b = r1[k][0, :n].cpu(), r60[k][u, :n].cpu()
+            assert torch.equal(a, b), (u, k, float((a - b).abs().max()))
+        assert torch.equal(r1["dict_attn"][0, 0].cpu()[:, :n], r60["dict_attn"][u, 0].cpu()[:, :n]), u
+        m1 = r1["mel2word"][0].cpu()
+        assert torch.equal(m1[m1 > 0], r60["mel2word"][u].cpu()[: int((m1 > 0).sum())]), u
