@@ -264,7 +264,7 @@ extern "C" int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMe
 // divides by 4, else 2, else 1): how many waves share the parts (KS = 4 / 2 / 1, chosen per launch from the grid size and the CU count)
 // does not change a single bit of the result, so an utterance gets the same log-durations alone and inside any batch.
 template <int ENGINE, int NT, int WC, int KS, int U, int PP>
-__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1 : 2) : (PP > 1 && ENGINE == ENG_BF16X6 ? 2 : 3)) void conv1d_short_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1 : 2) : 3) void conv1d_short_kernel(const ConvParams p) {
     constexpr int MT = 1, WT = 1;   // one 32-row time tile per workgroup
     static_assert(WC * KS == 4, "four waves: co-tile groups x contraction splits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -296,9 +296,12 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
     const int pitch = p.C_in_pad * ES + 16;   // +16 B: conflict-free ds_read_b128 across 16 rows ((C_in_pad * ES + 16) mod 256 == 16 for the widths in use)
     const int plane = rows * pitch;   // bytes between the planes of the staged tile
 
-    f32x16 accp[PP][MT][NT];
+    // accumulator sets: one per part when the parts of other waves arrive through LDS (KS > 1); a single wave (KS = 1) needs only two —
+    // the running total ((p0 + p1) + ..) and the part in progress
+    constexpr int NSET = KS == 1 ? (PP > 1 ? 2 : 1) : PP;
+    f32x16 accp[NSET][MT][NT];
 #pragma unroll
-    for (int pp = 0; pp < PP; ++pp)
+    for (int pp = 0; pp < NSET; ++pp)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
         bool valid;
         int co;
         float bias, bias_s;
-        float r1[16], r2[16];
+        float r1[16];   // (the second residual is rare on this kernel's layers: fetched in the epilogue, its 16 registers are worth a wave of occupancy)
     };
     auto epi_fetch = [&](int m, int n, EpiOperands& eo) {
         eo.valid = false;
@@ -390,19 +393,12 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
         const int tb = t0 + (wt * MT + m) * 32 + 4 * (lane >> 5);
         const long long row0 = (long long)b * p.y_bstride_rows;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) eo.r1[r] = eo.r2[r] = 0.f;
+        for (int r = 0; r < 16; ++r) eo.r1[r] = 0.f;
         if (sg.res) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int t = tb + (r & 3) + 8 * (r >> 2);
                 if (t < p.T_out && t < out_len) eo.r1[r] = sg.res[(row0 + t) * sg.ld_res + sg.coff_res + cs];
-            }
-        }
-        if (sg.res2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = tb + (r & 3) + 8 * (r >> 2);
-                if (t < p.T_out && t < out_len) eo.r2[r] = sg.res2[(row0 + t) * sg.ld_res2 + sg.coff_res2 + cs];
             }
         }
     };
@@ -451,9 +447,21 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
         int ctc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) ctc[n] = ct0 + n < NCT ? ct0 + n : NCT - 1;
-#pragma unroll
+        constexpr bool SEQ = KS == 1 && PP > 1;       // one wave sums all parts: each finished part is folded into the total at once
+        // (SEQ: a real loop — four unrolled copies of the contraction would cost the registers the two sets save; every part
+        // accumulates in set 1 and is added to the total in set 0, 0 + p0 being exact)
+#pragma unroll(SEQ ? 1 : PP)
         for (int pp = 0; pp < PP; ++pp) {
         const int part = ks * PP + pp;                // this wave's parts: ks * PP .. ks * PP + PP - 1
+        constexpr int SEQ_SET = 1;
+        if (SEQ && pp > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accp[1][m][n][r] = 0.f;
+        }
         const uint4* wp[3] = {(const uint4*)p.w_hi + (size_t)part * NGW * NCT * 64 + lane, (const uint4*)p.w_lo + (size_t)part * NGW * NCT * 64 + lane,
                               (const uint4*)p.w_lo2 + (size_t)part * NGW * NCT * 64 + lane};
         // two cursors over the part's step sequence (weights run PF steps ahead, activations one), advanced by adds; both stop on
@@ -500,13 +508,24 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
                 load_w(rw[(j + PF) % R]);
                 load_x(xa[(j + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s + j < S) mma(accp[pp], rw[j], xa[j & 1]);
+                if (s + j < S) {
+                    if constexpr (SEQ) mma(accp[SEQ_SET], rw[j], xa[j & 1]);
+                    else mma(accp[pp], rw[j], xa[j & 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (SEQ) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accp[0][m][n][r] += accp[1][m][n][r];
+        }
         }   // (parts of this wave)
         // ---- combine the P = KS * PP partial sums in the fixed order ((p0 + p1) + p2) + p3: this wave's own parts first ...
-        if (KS == 1 || ks == 0) {
+        if (KS > 1 && ks == 0) {
 #pragma unroll
             for (int pp = 1; pp < PP; ++pp)
 #pragma unroll
@@ -594,7 +613,10 @@ __global__ __launch_bounds__(256, U > 8 ? 1 : NT > 1 ? (ENGINE == ENG_BF16X6 ? 1
             }
             if (sg.res2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += eo.r2[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int dt = (r & 3) + 8 * (r >> 2);
+                    if (tb + dt < t_end) v[r] += sg.res2[(row0 + dt) * sg.ld_res2 + sg.coff_res2 + cs];
+                }
             }
             if (p.out_div != 1.f) {
 #pragma unroll

@@ -1353,5 +1353,8 @@ def test_results_do_not_depend_on_batch_composition(acoustic):
             a, b = r1[k][0, :n].cpu(), r60[k][u, :n].cpu()
             assert torch.equal(a, b), (u, k, float((a - b).abs().max()))
         assert torch.equal(r1["dict_attn"][0, 0].cpu()[:, :n], r60["dict_attn"][u, 0].cpu()[:, :n]), u
-        m1 = r1["mel2word"][0].cpu()
-        assert torch.equal(m1[m1 > 0], r60["mel2word"][u].cpu()[: int((m1 > 0).sum())]), u
+        # same integer durations: the batch row's frames are a prefix of the lone utterance's (alone, the <= 3 frames_multiple pad frames
+        # repeat the last word; inside a batch the row is zero-padded)
+        m60 = r60["mel2word"][u].cpu()
+        k = int((m60 > 0).sum())
+        assert k > 0 and torch.equal(r1["mel2word"][0].cpu()[:k], m60[:k]) and r1["mel2word"].shape[1] - k <= 3, u
