@@ -644,8 +644,8 @@ def main():
                        "utterances_per_gpu_per_batch": args.batch, "batches_per_step": steps_per_pass,
                        "distinct_batches": len([b for b in batches if b is not None]), "batch_shapes_B_Tw_Lk": shapes,
                        "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
-                       "all_forwards": {"n": (args.warmup + args.steps) * steps_per_pass,   # what a profiler attached to this run sees
-                                        "mel_frames": main_warm_frames + frames_rank},
+                       "all_forwards": {"n": (args.warmup + args.steps) * steps_per_pass + (guard_info["guarded_forwards"] if guard_info else 0),   # what a profiler attached to this run sees
+                                        "mel_frames": main_warm_frames + frames_rank + (guard_info["mel_frames"] if guard_info else 0)},   # (incl. the range-guard pass)
                        "step_includes": {"table": "H2D of the batch's ids + device prior sample + int16 conversion + D2H of the int16 waveforms "
                                                   "(dictionary resident in HBM: dtts_dict_table_upload, once)",
                                          "resident": "ids resident in HBM; fp32 waveform left in HBM",

@@ -17,6 +17,7 @@
 #include "rb_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace dtts {
@@ -234,13 +235,15 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     };
     const bool all_inb = base_t >= 0 && base_t + W <= len;   // block-uniform: no row of the tile needs masking
     int n_ovf = 0;
-    auto write_act = [&](const f32x16 (&v)[MT][NT]) {
-        if (DTTS_DBG(p, 8)) return;
+    // MASKED = false: a tile wholly inside its utterance (block-uniform, most tiles) — no row needs the zero select: 2 of the ~11 VALU
+    // instructions per four values less, in the phase that is VALU-bound (LABNOTES round 4 (C))
+    auto write_act_impl = [&](const f32x16 (&v)[MT][NT], auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = (wt * MT + m) * 32 + (lane & 31);
             const int t = base_t + row;
-            const bool inb = all_inb || (t >= 0 && t < len);
+            const bool inb = !MASKED || (t >= 0 && t < len);
             // range guard: only the rows this tile OUTPUTS are counted.  Every in-utterance row is an output row of exactly one tile
             // and carries the exact activation there at each of the six stages, so the count is a census; halo rows (recomputed,
             // increasingly inexact towards the tile edge, their results discarded) are another tile's output rows.
@@ -253,10 +256,17 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     const f32x4 v4 = {v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]};
                     uint2 pk = act4<EL>(v4, 0.1f);
                     if constexpr (GUARD) n_ovf += counted ? ovf4(v4, 0.1f) : 0;
-                    if (!all_inb && !inb) pk = make_uint2(0, 0);   // all_inb is block-uniform: interior tiles skip the selects
+                    if constexpr (MASKED) {
+                        if (!inb) pk = make_uint2(0, 0);
+                    }
                     *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
         }
+    };
+    auto write_act = [&](const f32x16 (&v)[MT][NT]) {
+        if (DTTS_DBG(p, 8)) return;
+        if (all_inb) write_act_impl(v, std::false_type{});
+        else write_act_impl(v, std::true_type{});
     };
 
     uint4 ring[4][NT];
