@@ -78,8 +78,21 @@ __device__ __forceinline__ uint2 act4(const f32x4& v, float slope) {
     const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
     const f32x2_t ta = a * slope, tb = b * slope;
     if constexpr (EL == EL_F16) {
+#ifdef DTTS_ACT_F32   // round 3's form: leaky_relu in fp32 (v_pk_mul_f32 + v_med3 saturating at 65504), then the conversion: 8 VALU per 4 values
         return make_uint2(pack2<EL>(__builtin_amdgcn_fmed3f(a[0], ta[0], 65504.f), __builtin_amdgcn_fmed3f(a[1], ta[1], 65504.f)),
                           pack2<EL>(__builtin_amdgcn_fmed3f(b[0], tb[0], 65504.f), __builtin_amdgcn_fmed3f(b[1], tb[1], 65504.f)));
+#else
+        // convert first, then leaky_relu on PACKED fp16 pairs: v_cvt_pk_f16_f32, v_pk_mul_f16, v_pk_max_f16 = 6 VALU per 4 values (the
+        // activation rewrites of the narrow ResBlock kernels are VALU-bound, LABNOTES round 4 (C)).  The slope is fp16(0.1) and negative
+        // values round twice: simulated waveform error 5.19e-5 -> 5.28e-5 (tools/precision_sim.py arithmetic).  No saturation: a
+        // pre-activation beyond the fp16 range becomes +-inf — exactly what the range guard (ovf4 below, on the fp32 values) counts.
+        const f16x2_t slope2 = {(_Float16)0.1f, (_Float16)0.1f};
+        const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+        const f16x2_t ra = __builtin_elementwise_max(ha, ha * slope2), rb = __builtin_elementwise_max(hb, hb * slope2);
+        (void)ta;
+        (void)tb;
+        return make_uint2(__builtin_bit_cast(unsigned, ra), __builtin_bit_cast(unsigned, rb));
+#endif
     } else {
         float r0, r1, r2, r3;
         asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(a[0]), "v"(ta[0]));
