@@ -222,8 +222,6 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // 2 PH rows): a private strip of TT rows per tile, so that no two workgroups read-modify-write the same rows
     const auto rs_s = p.s_private ? __builtin_amdgcn_make_buffer_rsrc((void*)p.S, 0, p.s_private, 0x00020000)
                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(p.S + brow * C), 0, len * C * 4, 0x00020000);
-    const int goff0 = p.s_private ? ((j * TT - H + r0) * C + c4 * 4) * 4
-                                  : ((base_t + r0) * C + c4 * 4) * 4;   // byte offset of (local row r0, column c4); may be negative
 
     // bf16(leaky_relu(v + bias, 0.1)) of this wave's tiles -> LDS activation buffer, zero outside the utterance.
     // bias: this lane's 4 channel quads per co-tile, loaded into registers BEFORE the contraction it follows.
@@ -337,15 +335,22 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // range check, halo rows are sent out of range explicitly.
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Sa ? p.Sa + brow * C : (unsigned short*)(p.S + brow * C)), 0,
                                                         len * C * 2, 0x00020000);
+    // WAVE-PRIVATE transposition: each wave stages its own 32 rows x its own CW channels and reads the same block back as whole 128-byte
+    // row segments (8 NT lanes per row): no workgroup barrier inside the epilogue (round 3: 2 MT - 1 of them), the waves drift through their
+    // slabs and HBM round trips independently.  (The LDS serves one wave's accesses in order.)
+    constexpr int CW = NT * 32, F4W = CW / 4, RPI = 64 / F4W, NRD = 32 / RPI;
+    const int er = lane / F4W, ec = lane % F4W;                          // row within an access, 16-byte chunk of the wave's row segment
+    const int goffw = (p.s_private ? (j * TT - H) * C : base_t * C) * 4 + (wc * CW + ec * 4) * 4;
+    auto erow = [&](int m, int u) { return (wt * MT + m) * 32 + u * RPI + er; };   // local tile row of (slab m, access u)
     auto eoff = [&](int m, int u) {
-        const int row = tile_row(m, u);
-        return (row >= H && row < H + TT) ? goff0 + (row - r0) * (C * 4) : (int)0x80000000;
+        const int row = erow(m, u);
+        return (row >= H && row < H + TT) ? goffw + row * (C * 4) : (int)0x80000000;
     };
-    u32x4 sold[MT][PER];
+    u32x4 sold[MT][NRD];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
+        for (int u = 0; u < NRD; ++u) {
             sold[m][u] = u32x4{0u, 0u, 0u, 0u};
             // (all ResBlocks in one launch: the sum was written by THIS workgroup a moment ago and sits in L2 / Infinity Cache: a cached read)
             if (mode >= 1) sold[m][u] = p.nrb > 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0)
@@ -356,9 +361,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     constexpr int OP = C * 4;                      // otile row pitch (bytes)
     char* otile = smem;
     char* estage = wav_now ? smem + (((size_t)TT * OP > (size_t)(W + 2 * RB_GUARD) * PITCH) ? (size_t)TT * OP : (size_t)(W + 2 * RB_GUARD) * PITCH) : stage;
+    char* stg = estage + (wt * 32) * EP + (wc * CW) * 4;                 // this wave's block of the staging buffer
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m) __syncthreads();
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -366,24 +371,26 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = xr[m][n][4 * q + e];
-                *(f32x4*)(estage + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+                *(f32x4*)(stg + (lane & 31) * EP + (n * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
             }
         // slab m of the residual registers is free: the NEXT tile's slab m starts its trip into them (no second register set, and
         // the loads are younger than the stage sum fetched above, so nothing below waits for them)
         if (has_next) load_x(xr[m], m, bn, t0n - H, lenn);
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
+        for (int u = 0; u < NRD; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(estage + (r0 + RPP * u) * EP + c4 * 16);
+            f32x4 o = *(const f32x4*)(stg + (u * RPI + er) * EP + ec * 16);
             o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
             if (wav_now) {
-                const int row = tile_row(m, u);                        // local tile row
+                const int row = erow(m, u);                            // local tile row
                 if (row >= H && row < H + TT) {
                     const int t = base_t + row;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (t >= 0 && t < len) ? lrelu(o[e] / p.div, p.slope) : 0.f;
-                    *(f32x4*)(otile + (size_t)(row - H) * OP + c4 * 16) = o;
+                    *(f32x4*)(otile + (size_t)(row - H) * OP + (wc * CW + ec * 4) * 4) = o;
                 }
                 continue;
             }
@@ -402,6 +409,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                 __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                               // slab m + 1 reuses this wave's staging block
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if constexpr (C == 32) if (wav_now) {   // (the launcher rejects p.wav for other widths)
         // ---- wav[t] = tanh(b + sum_{tap, c} w[c][tap] * otile[t + tap - 3][c])   (conv_post + tanh, hifigan.py:139-141) in exact fp32:
