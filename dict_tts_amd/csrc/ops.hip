@@ -691,7 +691,7 @@ __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, con
 // DM4: float4 pieces of a row per lane (3: the 768-wide gloss embeddings; 1: rows <= 256 wide = the PRE-PROJECTED table, K = key Wk^T /
 // V = value Wv^T, 192 wide); RU: 2 x the rows of a chunk (a wave keeps RU / 2 key rows + RU / 2 value rows, or RU aliased rows, in flight).
 template <int DM4, int RU>
-__global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
+__global__ __launch_bounds__(S2PA_NTHR, DM4 == 3 ? 5 : 1) void s2pa_kernel(const S2paArgs a) {
     __shared__ S2paShared sh;
     constexpr int S2PA_DMAX4 = DM4;   // (shadows the namespace constant: every per-lane row array below has DM4 pieces)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -720,29 +720,34 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     f32x4 acc[S2PA_DMAX4];
 #pragma unroll
     for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto fold = [&](const float (&lg)[RU], const f32x4 (&v)[RU][S2PA_DMAX4], int cnt) {
+    // (NR = rows of the chunk: the arithmetic is that of round 3's RU-row fold with its zero rows left out — exp(.) * 0 and + 0 are exact
+    // no-ops — so both input forms keep giving bit-identical results; the separate-values form no longer carries RU / 2 zero rows in
+    // registers: 104 -> <= 96 VGPRs = a fifth wave per SIMD, i.e. all live words of a B = 60 batch resident at once)
+    auto fold_n = [&](const auto& lg, const auto& v, int cnt, auto nr_tag) {
+        constexpr int NR = decltype(nr_tag)::value;
         float mn = m_run;
 #pragma unroll
-        for (int j = 0; j < RU; ++j)
+        for (int j = 0; j < NR; ++j)
             if (j < cnt) mn = fmaxf(mn, lg[j]);
         const float sc = expf(m_run - mn);
-        float e[RU];
+        float e[NR];
 #pragma unroll
-        for (int j = 0; j < RU; ++j) e[j] = j < cnt ? expf(lg[j] - mn) : 0.f;
+        for (int j = 0; j < NR; ++j) e[j] = j < cnt ? expf(lg[j] - mn) : 0.f;
 #pragma unroll
         for (int cc = 0; cc < S2PA_DMAX4; ++cc) {
             acc[cc] = acc[cc] * sc;
 #pragma unroll
-            for (int j = 0; j < RU; ++j) acc[cc] += v[j][cc] * e[j];
+            for (int j = 0; j < NR; ++j) acc[cc] += v[j][cc] * e[j];
         }
         m_run = mn;
     };
+
     constexpr int RV = RU / 2;   // rows folded together.  Row -> (wave, fold) assignment is the SAME with and without aliasing (chunk c
                                  // of RV rows goes to wave c % NW), so the two input forms give bit-identical results
     if (alias) {
         // two chunks (c, c + NW) of this wave in flight at once: 2 * RV rows = 12 independent 16-byte loads per lane
         for (int i = wave * RV; i < n; i += 2 * S2PA_NW * RV) {
-            f32x4 k[2][RU][S2PA_DMAX4];
+            f32x4 k[2][RV][S2PA_DMAX4];
             int lr[2][RV];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -758,13 +763,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
             for (int h = 0; h < 2; ++h) {
                 const int i0 = i + h * S2PA_NW * RV;
                 if (i0 >= n) break;
-#pragma unroll
-                for (int j = RV; j < RU; ++j)
-#pragma unroll
-                    for (int cc = 0; cc < S2PA_DMAX4; ++cc) k[h][j][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-                float lg[RU];
-#pragma unroll
-                for (int j = 0; j < RU; ++j) lg[j] = 0.f;
+                float lg[RV];
 #pragma unroll
                 for (int j = 0; j < RV; ++j) {
                     float d = 0.f;
@@ -775,12 +774,12 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
                     lg[j] = wave_sum(d);
                     if (lane == 0 && i0 + j < n) sh.lg[lr[h][j]] = lg[j];
                 }
-                if (!dead) fold(lg, k[h], min(n - i0, RV));
+                if (!dead) fold_n(lg, k[h], min(n - i0, RV), std::integral_constant<int, RV>{});
             }
         }
     } else {   // keys and values in flight together: one chunk per step
         for (int i = wave * RV; i < n; i += S2PA_NW * RV) {
-            f32x4 k[RV][S2PA_DMAX4], v[RU][S2PA_DMAX4];
+            f32x4 k[RV][S2PA_DMAX4], v[RV][S2PA_DMAX4];
             int lr[RV];
 #pragma unroll
             for (int j = 0; j < RV; ++j) {
@@ -793,13 +792,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
                     v[j][cc] = (lane + 64 * cc < D4 && !dead) ? vr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-#pragma unroll
-            for (int j = RV; j < RU; ++j)
-#pragma unroll
-                for (int cc = 0; cc < S2PA_DMAX4; ++cc) v[j][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float lg[RU];
-#pragma unroll
-            for (int j = 0; j < RU; ++j) lg[j] = 0.f;
+            float lg[RV];
 #pragma unroll
             for (int j = 0; j < RV; ++j) {
                 float d = 0.f;
@@ -809,7 +802,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
                 lg[j] = wave_sum(d);
                 if (lane == 0 && i + j < n) sh.lg[lr[j]] = lg[j];
             }
-            if (!dead) fold(lg, v, min(n - i, RV));
+            if (!dead) fold_n(lg, v, min(n - i, RV), std::integral_constant<int, RV>{});
         }
     }
 #pragma unroll
