@@ -691,7 +691,7 @@ __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, con
 // DM4: float4 pieces of a row per lane (3: the 768-wide gloss embeddings; 1: rows <= 256 wide = the PRE-PROJECTED table, K = key Wk^T /
 // V = value Wv^T, 192 wide); RU: 2 x the rows of a chunk (a wave keeps RU / 2 key rows + RU / 2 value rows, or RU aliased rows, in flight).
 template <int DM4, int RU>
-__global__ __launch_bounds__(S2PA_NTHR, DM4 == 3 ? 5 : 1) void s2pa_kernel(const S2paArgs a) {
+__global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     __shared__ S2paShared sh;
     constexpr int S2PA_DMAX4 = DM4;   // (shadows the namespace constant: every per-lane row array below has DM4 pieces)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -721,8 +721,8 @@ __global__ __launch_bounds__(S2PA_NTHR, DM4 == 3 ? 5 : 1) void s2pa_kernel(const
 #pragma unroll
     for (int cc = 0; cc < S2PA_DMAX4; ++cc) acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (NR = rows of the chunk: the arithmetic is that of round 3's RU-row fold with its zero rows left out — exp(.) * 0 and + 0 are exact
-    // no-ops — so both input forms keep giving bit-identical results; the separate-values form no longer carries RU / 2 zero rows in
-    // registers: 104 -> <= 96 VGPRs = a fifth wave per SIMD, i.e. all live words of a B = 60 batch resident at once)
+    // no-ops — so both input forms keep giving bit-identical results.  Forcing a fifth wave per SIMD on the 768-wide form (104 -> 96 VGPRs,
+    // 29 spilled) so that all live words of a B = 60 batch are resident at once: 96 -> 99 us, not kept)
     auto fold_n = [&](const auto& lg, const auto& v, int cnt, auto nr_tag) {
         constexpr int NR = decltype(nr_tag)::value;
         float mn = m_run;
