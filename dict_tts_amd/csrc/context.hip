@@ -1032,7 +1032,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     // which stages run ALL their ResBlocks in one launch (rblock.hip; OPT-IN, tune bit 9 — measured: HBM traffic -0.36 MB / mel frame, vocoder
     // alone +1.1 %, pipelined step +1.9 %: LABNOTES round 4): C <= 64, every ResBlock has a whole-ResBlock kernel, and the batch has at least
     // two tiles per CU (small grids keep one launch per ResBlock: half-size tiles fill the chip there)
-    bool fuse_stage[8] = {};
+    int fuse_n[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // ResBlocks in the stage's FIRST launch (1 = one launch per ResBlock)
     size_t s_elems = max_elems;   // capacity of the stage-sum buffer
     {
         long long rows = T;
@@ -1040,6 +1040,13 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         for (int i = 0; i < nup; ++i) {
             rows *= c.upsample_rates[i];
             ch /= 2;
+            // (experiment, tune bit 12) C = 32 only: the first TWO ResBlocks in one launch — the k = 3 launch alone is HBM-bound (x in, stage sum out:
+            // 4.6 TB/s), together with k = 7 its bytes ride on that launch's compute; the last ResBlock (fused conv_post) stays on its own
+            if (fuse && (h->tune & 4096) && !(h->tune & 512) && nk == 3 && ch == 32 && !h->rbf1[(size_t)i * nk].empty() && !h->rbf1[(size_t)i * nk + 1].empty()) {
+                const int k2 = std::max(h->rbf1[(size_t)i * nk][0].K, h->rbf1[(size_t)i * nk + 1][0].K), TT2 = 1024 - 12 * (k2 - 1);
+                if (TT2 >= 64 && (long long)B * ((rows + TT2 - 1) / TT2) >= 2LL * h->n_cu) fuse_n[i] = 2;
+                continue;
+            }
             bool all = fuse && (h->tune & 512) && nk >= 2 && nk <= 3 && (ch == 32 || ch == 64);
             int kmax = 0;
             for (int j = 0; j < nk && all; ++j) {
@@ -1054,7 +1061,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 if (prow <= 0 || (size_t)prow * ch * sizeof(float) >= (size_t)INT_MAX) continue;
                 s_elems = std::max(s_elems, (size_t)prow * ch);
             }
-            fuse_stage[i] = true;
+            fuse_n[i] = nk;
         }
     }
     const size_t s_cap_bytes = s_elems * sizeof(float);
@@ -1174,10 +1181,11 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 };
                 // ALL ResBlocks of a C <= 64 stage in ONE launch (rblock.hip: work items (tile, ResBlock)): x crosses HBM once per tile and the
                 // stage sum is accumulated through L2 / Infinity Cache.  Opt-in: tune bit 9
-                const bool stage_fused = fuse_stage[i];
-                if (stage_fused && j > 0) continue;        // (launched with j = 0)
-                const int j_last = stage_fused ? nk - 1 : j;
-                rp.nrb = stage_fused ? nk : 1;
+                if (j > 0 && j < fuse_n[i]) continue;      // (launched with j = 0)
+                const int j_last = j == 0 ? fuse_n[i] - 1 : j;
+                const bool stage_fused = fuse_n[i] == nk;
+                rp.nrb = j_last - j + 1;
+                rp.last_mode = j_last == nk - 1 ? 2 : 1;
                 rp.K = 0;
                 for (int jj = j; jj <= j_last; ++jj) {
                     fill_set(rp.rb[jj - j], jj);

@@ -25,7 +25,8 @@ struct RBlockParams {
     const int* lens;       // [B] valid rows
     int B, T;
     int K;                 // the LARGEST kernel size of the launch: the tile's halo is 6 (K - 1) rows per side
-    int mode;              // nrb = 1: 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa.  nrb > 1: ignored (0, 1.., 2 in turn)
+    int mode;              // what the (first) ResBlock of the launch does with the stage sum: 0: xs = r ; 1: xs += r ; 2: xs = (xs + r) / div, and emit Sa
+    int last_mode;         // nrb > 1: the same for the launch's LAST ResBlock (2 when it is the stage's last, else 1); those in between accumulate (1)
     int drop_S;            // mode 2 with Sa: do not write the fp32 xs (nothing reads it after the stage)
     float div, slope;
     // fused conv_post + tanh (last stage, mode 2, C = 32): the stage output never reaches HBM, the waveform is written instead

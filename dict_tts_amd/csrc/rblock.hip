@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     const int S = DTTS_DBG(p, 1) ? 0 : (REAL_STEPS ? Kr : R.Kp) * NKG;   // k-steps (packed taps are zero padded so that Kp * NKG % 4 == 0)
     const bool last_rb = !PS || r + 1 == p.nrb;
     // what the epilogue does with the stage sum: one ResBlock per launch: p.mode; all of the stage's: write, accumulate.., finish
-    const int mode = (!PS || p.nrb == 1) ? p.mode : (r == 0 ? 0 : (last_rb ? 2 : 1));
-    const bool wav_now = p.wav && last_rb;
+    const int mode = (!PS || p.nrb == 1 || r == 0) ? p.mode : (last_rb ? p.last_mode : 1);
+    const bool wav_now = p.wav && last_rb;           // (the launcher accepts p.wav only on a launch that ends its stage: last_mode 2)
     t0 = __builtin_amdgcn_readfirstlane(t0);
     const int base_t = t0 - H;  // global time of local row 0
     const long long brow = (long long)b * p.T;
