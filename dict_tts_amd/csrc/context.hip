@@ -1210,6 +1210,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 rp.el = el;
                 rp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                 rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
+                rp.small_tile = (h->tune & 16384) ? 1 : 0;
                 rp.pingpong = (h->tune & 128) ? 1 : 0;   // tune bit 7: the two-group form of rblock2.hip (experiment)
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");

@@ -37,6 +37,7 @@ struct RBlockParams {
     unsigned* tile_ctr;    // persistent configurations: device counter (zero at launch) for dynamic tile claiming, or null = static w, w + G, ...
     int pre_off;           // (set by the launcher) byte offset of the tile-count table in dynamic LDS
     unsigned long long* ovf;   // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null
+    int small_tile;        // tune bit 14: C = 64 keeps 512-row tiles at k >= 7 (A/B against the default 640)
     int pingpong;          // 1: the phase-shifted two-group form (rblock2.hip; an experiment, dtts_config.tune_flags bit 7)
     int s_private;         // 0, or the byte capacity of S when it holds one private TT-row strip per TILE (fused launch + fused conv_post)
     unsigned long long* stats;   // -DDTTS_ABLATE builds only (DTTS_RB_STATS): per-phase cycle sums of each group's wave 0 (rblock2.hip)

@@ -569,6 +569,9 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
     if (C == 128 && few(256)) return rb_launch_cfg<128, 4, 1, 1, 4, EL, 1>(p, stream);   // 128-row tile, 4 waves
     if (C == 256 && few(128)) return rb_launch_cfg<256, 2, 1, 1, 8, EL, 1>(p, stream);   // 64-row tile
     if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1, EL, 0>(p, stream);      // 512-row tile, 4 waves over time
+    // C = 64, k >= 7: 640-row tiles (MT = 5; the halo 12 (k - 1) is 11 / 19 % of the tile instead of 14 / 23 %: -4.8 % at k = 11, nothing at k = 3
+    // where 13 spilled registers cost what the halo gives); tune bit 14: 512-row tiles for every k (round 3)
+    if (C == 64 && p.K >= 7 && !p.small_tile) return rb_launch_cfg<64, 5, 1, 4, 2, EL, 1>(p, stream);
     if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
     if (C == 128) return rb_launch_cfg<128, 4, 1, 2, 4, EL, 1>(p, stream);    // 256-row tile, 8 waves (2 time x 4 channel)
     if (C == 256) return rb_launch_cfg<256, 4, 1, 1, 8, EL, 1>(p, stream);    // 128-row tile, 8 waves over channels

@@ -106,7 +106,7 @@ typedef struct dtts_config {
                                          own kernel, 1 upsamplers without the zero-tap skip, 2 static tile assignment, 3 no whole-ResBlock fusion
                                          at C >= 128, 4 per-launch timer events, 5 128-row tiles for the narrow upsamplers, 7 two-group phase-shifted ResBlock kernel at
                                          C = 32 (rblock2.hip), 9 all ResBlocks of a C <= 64 stage in one launch (less HBM traffic, not faster), 12 the first two ResBlocks of the
-                                         C = 32 stage in one launch (neutral).  (Builds made with
+                                         C = 32 stage in one launch (neutral), 14 512-row tiles for every k at C = 64.  (Builds made with
                                          -DDTTS_ABLATE — `make ablate`, tools/ab_*.sh — additionally OR the DTTS_TUNE environment variable in and
                                          honour a few more schedule-only variables; the release library has no such code.) */
 } dtts_config;

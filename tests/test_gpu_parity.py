@@ -1268,7 +1268,8 @@ def test_memory_safety_other_kernel_families(voc_sd):
 
 @pytest.mark.parametrize("flag,what", [(128, "two-group phase-shifted C = 32 ResBlock kernel (rblock2.hip)"),
                                        (512, "all ResBlocks of a C <= 64 stage in one launch, private stage-sum strips under the fused conv_post"),
-                                       (4096, "the first two ResBlocks of the C = 32 stage in one launch")])
+                                       (4096, "the first two ResBlocks of the C = 32 stage in one launch"),
+                                       (16384, "512-row tiles for every k of the C = 64 whole-ResBlock kernel (the default takes 640 rows at k >= 7)")])
 def test_optin_resblock_forms_are_bit_identical_to_the_default(voc_sd, voc_plain, flag, what):
     """round 4's two measured-and-not-adopted ResBlock forms (dtts_config.tune_flags bits 7 and 9; LABNOTES round 4) compute the SAME bits
     as the default launches — 70 ragged utterances (several tiles per persistent workgroup, odd tile counts, empty rows) and a B = 24 batch
