@@ -40,6 +40,7 @@ PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 / fp16 MFMA (MI355X_M
 PEAK_HBM_GBS = 8000.0
 DUR_BIAS = 3.09                        # exp(softplus(3.09)) - 1 ~= 22 frames per word
 N_TEST = 200                           # Biaobei test rows (label_set0.csv)
+C5_BATCH = 128                         # BASELINE.json configs[4]: batch=128 mixed-length (over 4 GPUs there)
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU leg
@@ -217,7 +218,7 @@ def main():
     ap.add_argument("--batch", type=int, default=60)
     ap.add_argument("--precision", choices=["f16", "bf16", "bf16x3"], default="f16",
                     help="vocoder arithmetic (include/dicttts_hip.h): f16 = the waveform-exact default")
-    ap.add_argument("--workload", choices=["rotating", "testset"], default="rotating")
+    ap.add_argument("--workload", choices=["rotating", "testset", "config5"], default="rotating")
     ap.add_argument("--input", choices=["table", "resident", "tensors"], default="table",
                     help="what a timed step includes: table = ids H2D + int16 waveform D2H (default); resident = ids already in "
                          "HBM, fp32 waveform stays in HBM; tensors = the reference API, keys/values uploaded per batch")
@@ -285,12 +286,24 @@ def main():
     hop = voc.hop
     # ---- the dictionary: resident in HBM, uploaded once (not part of a step)
     st = synth.biaobei_struct()
-    table = synth.dict_table(1234)
+    c5_sents = None
+    if args.workload == "config5":   # BASELINE configs[4]: the FULL zh-dict.json entry set resident (7,030 entries), B = 128 mixed-length utterances
+        full = synth.zh_dict_struct()
+        table = synth.dict_table(1234, full["entries"])
+        c5_sents = synth.config5_sentences(C5_BATCH, 55, full["entries"])
+    else:
+        table = synth.dict_table(1234)
     m.upload_dict_table(table)
     live_rows_of_entry = np.add.reduceat((table["key_map"] != 0).astype(np.int64), table["tok_off"][:-1])
 
     # ---- this rank's batches (host side, pinned): sentence index lists
-    if args.workload == "testset":
+    if args.workload == "config5":   # ONE batch of 128 utterances per step, utterance i -> rank i mod N (4 GPUs x 32 in BASELINE.json)
+        idx_lists = shard_indices(C5_BATCH, rank, world, (C5_BATCH + world - 1) // world)
+        steps_per_pass = n_steps(C5_BATCH, world, (C5_BATCH + world - 1) // world)
+        assert steps_per_pass == 1 and len(idx_lists) <= 1
+        idx_lists = idx_lists + [None] * (steps_per_pass - len(idx_lists))
+        args.batch = max(args.batch, (C5_BATCH + world - 1) // world)   # (sizes the pinned waveform buffers)
+    elif args.workload == "testset":
         idx_lists = shard_indices(N_TEST, rank, world, args.batch)
         steps_per_pass = n_steps(N_TEST, world, args.batch)
         idx_lists = idx_lists + [None] * (steps_per_pass - len(idx_lists))   # ranks without a batch in the tail chunk still step
@@ -302,7 +315,7 @@ def main():
     def host_batch(idx):
         if idx is None:
             return None
-        sent = [st["sentences"][i] for i in idx]
+        sent = [(c5_sents if c5_sents is not None else st["sentences"])[i] for i in idx]
         ib = synth.make_id_batch(sent, table)
         hb = {k: T(ib[k]).pin_memory() for k in ("word_tokens", "entry_ids", "pron_modified")}
         hb.update(B=len(sent), T_w=int(ib["word_tokens"].shape[1]), L_k=int(ib["L_k"]), P=int(ib["P"]), sent=sent)
@@ -602,6 +615,10 @@ def main():
         # meets_waveform_gate is MEASURED below (cpu_baseline leg: oracle waveforms of utterances 0..2) — null when that leg is off
         modes = {args.precision: {"vocoder_kernel_ms_per_forward": iso_ms, "vocoder_mel_frames_per_s": fr_l / (iso_ms * 1e-3),
                                   "meets_waveform_gate": None, "range_guard": guard_info}}
+        if args.precision == "f16":   # the fp16 decision (include/dicttts_hip.h): static bound + the always-on conv_post detector over EVERY forward of this run
+            torch.cuda.synchronize()
+            modes["f16"]["fp16_validity"] = {"static": voc.fp16_status, "worst_case_bound_mel6": voc.fp16_bound[0], "rms_estimate_mel6": voc.fp16_bound[1],
+                                             "nonfinite_outputs_all_forwards": int(voc.ctx.vocoder_nonfinite())}
         other = "bf16" if args.precision != "bf16" else "f16"
         voc2 = vocoder.HifiGAN(state_dict=voc_sd, config=synth.hifigan_config(), precision=abi.VOC_PRECISIONS[other])
         o_ms, _ = isolated(voc2)
@@ -640,7 +657,9 @@ def main():
                                     "durations (~22 frames/char); the step rotates over 4 different batches of the 200-sentence test set"
                                     if args.workload == "rotating" else
                                     "BASELINE configs[2]: one step = all 200 test sentences, utterance i -> rank i mod N in batches <= 60 "
-                                    "(tts_base.py:148-151)"),
+                                    "(tts_base.py:148-151)" if args.workload == "testset" else
+                                    "BASELINE configs[4]: dictionary stress — all 7,030 zh-dict.json entries resident, one step = ONE batch of 128 "
+                                    "mixed-length utterances (6..60 characters, heteronyms x5), utterance i -> rank i mod N (tts_base.py:148-151)"),
                        "utterances_per_gpu_per_batch": args.batch, "batches_per_step": steps_per_pass,
                        "distinct_batches": len([b for b in batches if b is not None]), "batch_shapes_B_Tw_Lk": shapes,
                        "mel_frames_per_step_per_gpu": frames_rank // max(args.steps, 1),
@@ -683,7 +702,8 @@ def main():
             if modes:   # the gate of each listed mode, measured against the oracle's waveforms (and, for f16, a clean range guard)
                 wc = cb["waveform_check"]
                 modes[args.precision]["waveform_check"] = {k: wc[k] for k in ("rms_diff", "abs_rms_delta", "frames", "pass")}
-                modes[args.precision]["meets_waveform_gate"] = bool(wc["pass"] and (guard_info is None or guard_info["clamped_activations"] == 0))
+                modes[args.precision]["meets_waveform_gate"] = bool(wc["pass"] and (guard_info is None or guard_info["clamped_activations"] == 0) and
+                                                                    modes[args.precision].get("fp16_validity", {}).get("nonfinite_outputs_all_forwards", 0) == 0)
                 wc2 = waveform_check(np, voc2, kept_all)
                 modes[other]["waveform_check"] = {k: wc2[k] for k in ("rms_diff", "abs_rms_delta", "frames", "pass")}
                 modes[other]["meets_waveform_gate"] = bool(wc2["pass"])

@@ -23,7 +23,7 @@ EXPORTS = ["dtts_default_config", "dtts_config_sizeof", "dtts_create", "dtts_des
            "dtts_finalize_weights", "dtts_dict_table_upload", "dtts_text2mel_encode", "dtts_text2mel_encode_ids", "dtts_text2mel_decode", "dtts_text2mel_fetch",
            "dtts_load_weights", "dtts_text2mel_plan", "dtts_text2mel_forward", "dtts_text2mel_forward_ids",
            "dtts_length_regulate", "dtts_hifigan_forward", "dtts_hifigan_hop", "dtts_wav_to_int16", "dtts_fft_blocks_forward",
-           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset", "dtts_set_noise_seed", "dtts_vocoder_range_guard", "dtts_vocoder_clamped",
+           "dtts_timer_enable", "dtts_timer_read", "dtts_timer_reset", "dtts_set_noise_seed", "dtts_vocoder_range_guard", "dtts_vocoder_clamped", "dtts_vocoder_nonfinite", "dtts_vocoder_fp16_bound",
            "dtts_debug_check", "dtts_debug_poke"]
 
 
@@ -93,6 +93,8 @@ def load_library(path=None):
     lib.dtts_set_noise_seed.argtypes = [vp, C.c_uint64]
     lib.dtts_vocoder_range_guard.argtypes = [vp, i32]
     lib.dtts_vocoder_clamped.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
+    lib.dtts_vocoder_nonfinite.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.dtts_vocoder_fp16_bound.argtypes = [vp, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dtts_debug_check.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.dtts_debug_poke.argtypes = [vp, vp]
     _lib = lib
@@ -251,3 +253,16 @@ class Context:
         n = C.c_int64(0)
         self._chk(self.lib.dtts_vocoder_clamped(self.h, C.byref(n), int(bool(reset)), stream), "dtts_vocoder_clamped")
         return n.value
+
+    def vocoder_nonfinite(self):
+        """cumulative count of non-finite pre-tanh samples the always-on conv_post detector saw (no synchronisation: valid for every
+        forward whose stream the caller has synchronised with)"""
+        n = C.c_int64(0)
+        self._chk(self.lib.dtts_vocoder_nonfinite(self.h, C.byref(n)), "dtts_vocoder_nonfinite")
+        return n.value
+
+    def vocoder_fp16_bound(self, mel_abs_max=6.0):
+        """(worst_case, rms_estimate) of the values the ResBlocks round to fp16 for |mel| <= mel_abs_max (dtts_vocoder_fp16_bound)"""
+        wc, est = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.dtts_vocoder_fp16_bound(self.h, C.c_float(mel_abs_max), C.byref(wc), C.byref(est)), "dtts_vocoder_fp16_bound")
+        return wc.value, est.value

@@ -52,10 +52,11 @@ struct Arena {
     bool debug = false;
     struct Buf { size_t start, bytes; };
     std::vector<Buf> bufs;   // debug: the buffers handed out since the last reserve / rewind
+    static constexpr int DBG_BUFS = 1024;   // debug mode budgets red zones for this many buffers per forward (the largest forward hands out < 100)
     hipError_t reserve(size_t n, hipStream_t s) {
         off = 0;
         bufs.clear();
-        if (debug) n += 128 * (RZ + 256);
+        if (debug) n += (size_t)DBG_BUFS * (RZ + 256);   // red zones + alignment of up to DBG_BUFS buffers (alloc fails beyond: see below)
         if (n > cap) {
             if (base) {
                 hipError_t e = hipDeviceSynchronize();
@@ -169,6 +170,13 @@ struct dtts_ctx {
     unsigned long long noise_seed = 0;              // per context (dtts_create: time, pid, device, instance; dtts_set_noise_seed overrides)
     unsigned long long* ovf_dev = nullptr;          // fp16 range guard counter (DTTS_VOC_F16), device
     bool guard_on = false;
+    // always-on overflow detector of the 16-bit vocoder modes: non-finite pre-tanh values counted by the conv_post epilogue (device), and the
+    // pinned host word every dtts_hifigan_forward copies it to behind its last kernel (dtts_vocoder_nonfinite reads it without a sync)
+    unsigned* bad_dev = nullptr;
+    volatile unsigned* bad_host = nullptr;
+    // static fp16 analysis of the ResBlock operands (build_vocoder): bound(M) <= wc_lin * M + wc_const for |mel| <= M (worst case, L1),
+    // est_lin * M + est_const = the propagated RMS (an ESTIMATE under independence); 0 / 0 when the mode has no fp16 operands
+    double wc_lin = 0, wc_const = 0, est_lin = 0, est_const = 0;
     bool voc_span = false;                          // DTTS_TIMER_VOC_CONV: one event pair spans the whole kernel family of a forward (below)
     int amax_cap = 0;
     int B = 0, T_w = 0, L_k = 0, P = 0, T_mel = 0;
@@ -334,7 +342,7 @@ bool pack_conv(dtts_ctx* h, PackedConv& L, int engine, int C_out, int C_in, int 
     if (engine == ENG_F32) {
         L.w_hi = upload(h, wf);
         // + the same weights as three bf16 pieces in k-groups of 16 (conv1d.h: ENG_BF16X6) for the short-sequence kernel
-        if (!(h->tune & 131072) && L.C_in_pad % 16 == 0) {   // DTTS_TUNE bit 17: fp32 MFMA only
+        if (!DTTS_TUNE(h, 131072) && L.C_in_pad % 16 == 0) {   // DTTS_TUNE bit 17: fp32 MFMA only
             const int KG6 = 16, E6 = 8, NG6 = L.C_in_pad / KG6;
             std::vector<uint16_t> pc[3];
             for (auto& v : pc) v.assign(n, 0);
@@ -463,7 +471,7 @@ bool pack_transposed(dtts_ctx* h, Need& need, PackedConv& L, int engine, const s
             return (j >= 0 && j < k) ? pw[((size_t)ci * C_out + co) * k + j] : 0.f;
         },
         bias, 1, 1, pad, 0, 2.0 * C_in * C_out * k /* per INPUT row: u outputs x k/u taps */);
-    L.poly_half = (half && !(h->tune & 2)) ? 1 : 0;
+    L.poly_half = (half && !DTTS_TUNE(h, 2)) ? 1 : 0;
     return ok;
 }
 
@@ -566,13 +574,13 @@ int build_acoustic(dtts_ctx* h) {
     h->dur_bias = upload_named(h, need, m + "dur_predictor.linear.0.bias");
     ok = ok && h->dur_w && h->dur_bias;
     // FVAE
-    ok = ok && pack_plain(h, need, h->g_pre, (c.decoder_fp32 || (h->tune & 1024)) ? ENG_F32 : ENG_BF16X3, m + "fvae.g_pre_net.0", 1, 4, 2);   // DTTS_TUNE bit 10: fp32 (round 2)
+    ok = ok && pack_plain(h, need, h->g_pre, (c.decoder_fp32 || DTTS_TUNE(h, 1024)) ? ENG_F32 : ENG_BF16X3, m + "fvae.g_pre_net.0", 1, 4, 2);   // DTTS_TUNE bit 10: fp32 (round 2)
     // g_pre_net = Conv1d(k = 8, stride 4, pad 2) as a STRIDE-1, 3-tap convolution over 4-frame groups: [B][T][C] is also [B][T/4][4C]
     // (T is a multiple of frames_multiple = 4), out[q] = sum_j W_j x[4q + j - 2] reads group q - 1 (frames 2, 3), q (all four) and q + 1
     // (frames 0, 1) — on the split-operand vconv kernel, which skips the two all-zero half taps per input chunk (vconv.hip: in_half).
     // DTTS_TUNE bit 16: the strided form on the generic kernel.
     h->g_pre_poly = PackedConv();
-    if (ok && !c.decoder_fp32 && !(h->tune & 1024) && !(h->tune & 65536) && c.frames_multiple == 4 && c.hidden_size % 64 == 0) {
+    if (ok && !c.decoder_fp32 && !DTTS_TUNE(h, 1024) && !DTTS_TUNE(h, 65536) && c.frames_multiple == 4 && c.hidden_size % 64 == 0) {
         const HostTensor* wg = folded_weight(h, need, m + "fvae.g_pre_net.0");
         std::vector<float> bg = bias_of(need, m + "fvae.g_pre_net.0");
         if (wg && wg->shape.size() == 3 && wg->shape[2] == 8 && !bg.empty()) {
@@ -591,7 +599,7 @@ int build_acoustic(dtts_ctx* h) {
     int parity = 0;
     // one fused kernel for the whole prior flow where the configuration allows (DTTS_TUNE bit 8: launch by launch again)
     bool fuse_flows = flowstack_supported(c.prior_glow_hidden, c.glow_kernel_size, c.prior_glow_n_layers, c.prior_glow_n_blocks, c.latent_size) &&
-                      !(h->tune & 256);
+                      !DTTS_TUNE(h, 256);
     std::vector<float> fs_host, fs_cond_w, fs_cond_b;
     for (int f = c.prior_glow_n_blocks - 1; ok && f >= 0; --f) {
         // reversed(flows): Flip, then the coupling layer (glow_modules.py:157-163).  The flip is not executed:
@@ -660,7 +668,7 @@ int build_acoustic(dtts_ctx* h) {
         const int n_c = (int)fs_cond_b.size(), Cg = c.hidden_size;
         const float* pc = fs_cond_w.data();
         // (split-bf16 operands on the vconv kernel like the WaveNet layers it conditions, unless the exact-fp32 decoder was asked for)
-        ok = ok && h->fs_w && pack_conv(h, h->fs_cond, (c.decoder_fp32 || Cg % 64 || n_c % 256 || (h->tune & 2048)) ? ENG_F32 : ENG_BF16X3, n_c, Cg, 1,
+        ok = ok && h->fs_w && pack_conv(h, h->fs_cond, (c.decoder_fp32 || Cg % 64 || n_c % 256 || DTTS_TUNE(h, 2048)) ? ENG_F32 : ENG_BF16X3, n_c, Cg, 1,
                                          [=](int co, int ci, int) { return pc[(size_t)co * Cg + ci]; }, fs_cond_b, 1, 1, 0);
     }
     ok = ok && pack_transposed(h, need, h->dec_pre, ENG_F32, m + "fvae.decoder.pre_net.0", 4, 0);
@@ -678,6 +686,115 @@ int build_acoustic(dtts_ctx* h) {
     return DTTS_OK;
 }
 
+// Static fp16 analysis of the ResBlock operands (VERDICT r4 #3a).  The fused kernels round leaky_relu(x) and leaky_relu(xt) to fp16 in all 72
+// ResBlock convolutions, where the reference computes in fp32 (modules/hifigan/hifigan.py:51-58).  Propagated from |mel| <= M through the
+// folded weights, per channel:
+//   worst case (a PROOF when it stays below 65504):  u_out[co] = |b[co]| + sum_ci u_in[ci] * sum_k |w[co][ci][k]|   (transposed convolutions:
+//     the largest output phase), leaky_relu does not grow a bound, the residual adds, the stage output is the mean of its ResBlocks;
+//   RMS estimate (NOT a proof: independent, zero-mean terms):  m_out[co] = b^2 + sum_ci m_in[ci] * sum_k w^2, leaky_relu halves it.
+// Both are affine in M (M^2 for the second moments), so two evaluations give coefficients for any mel range: dtts_vocoder_fp16_bound.
+// For real checkpoints the worst case is astronomically loose (it compounds sum|w| ~ 10-40 per convolution over 6 convolutions per
+// ResBlock): it proves small-gain generators only.  Everything else runs fp16 under the always-on detector (conv_post epilogue).
+bool vocoder_fp16_analysis(dtts_ctx* h, Need& need) {
+    const dtts_config& c = h->cfg;
+    const std::string v = "vocoder.";
+    const int nk = c.n_resblock_kernels;
+    double peak_wc[2] = {0, 0}, peak_m2[2] = {0, 0};   // [pass]: pass 0 = M = 0 (the bias part), pass 1 = M = 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const double M = pass;
+        auto conv = [&](const std::string& base, const std::vector<double>& uin, const std::vector<double>& min, std::vector<double>& uout,
+                        std::vector<double>& mout) -> bool {   // Conv1d weight [co][ci][k]
+            const HostTensor* w = folded_weight(h, need, base);
+            const std::vector<float> b = bias_of(need, base);
+            if (!w || b.empty() || w->shape.size() != 3) return false;
+            const int co_n = (int)w->shape[0], ci_n = (int)w->shape[1], k_n = (int)w->shape[2];
+            if ((int)uin.size() < ci_n) return false;
+            uout.assign(co_n, 0.0);
+            mout.assign(co_n, 0.0);
+            for (int co = 0; co < co_n; ++co) {
+                double su = std::fabs((double)b[co]), sm = (double)b[co] * b[co];
+                for (int ci = 0; ci < ci_n; ++ci) {
+                    double a1 = 0, a2 = 0;
+                    const float* pw = &w->f[((size_t)co * ci_n + ci) * k_n];
+                    for (int k = 0; k < k_n; ++k) {
+                        a1 += std::fabs((double)pw[k]);
+                        a2 += (double)pw[k] * pw[k];
+                    }
+                    su += a1 * uin[ci];
+                    sm += a2 * min[ci];
+                }
+                uout[co] = su;
+                mout[co] = sm;
+            }
+            return true;
+        };
+        std::vector<double> u(c.audio_num_mel_bins, M), m(c.audio_num_mel_bins, M * M), u2, m2;
+        if (!conv(v + "conv_pre", u, m, u2, m2)) return false;
+        u.swap(u2);
+        m.swap(m2);
+        for (int i = 0; i < c.n_upsamples; ++i) {
+            const int r = c.upsample_rates[i], k_n = c.upsample_kernel_sizes[i], pad = (k_n - r) / 2;
+            const HostTensor* w = folded_weight(h, need, v + "ups." + std::to_string(i));   // ConvTranspose1d [ci][co][k]
+            const std::vector<float> b = bias_of(need, v + "ups." + std::to_string(i));
+            if (!w || b.empty() || w->shape.size() != 3 || (int)w->shape[2] != k_n) return false;
+            const int ci_n = (int)w->shape[0], co_n = (int)w->shape[1];
+            std::vector<double> ux(co_n, 0.0), mx(co_n, 0.0);
+            for (int co = 0; co < co_n; ++co)
+                for (int ph = 0; ph < r; ++ph) {   // output phase ph collects the taps k == ph + pad (mod r)
+                    double su = std::fabs((double)b[co]), sm = (double)b[co] * b[co];
+                    for (int ci = 0; ci < ci_n; ++ci) {
+                        const float* pw = &w->f[((size_t)ci * co_n + co) * k_n];
+                        double a1 = 0, a2 = 0;
+                        for (int k = (ph + pad) % r; k < k_n; k += r) {
+                            a1 += std::fabs((double)pw[k]);
+                            a2 += (double)pw[k] * pw[k];
+                        }
+                        su += a1 * u[ci];                    // leaky_relu(0.1) in front does not grow the bound
+                        sm += a2 * 0.505 * m[ci];
+                    }
+                    ux[co] = std::max(ux[co], su);
+                    mx[co] = std::max(mx[co], sm);
+                }
+            std::vector<double> us(co_n, 0.0), ms(co_n, 0.0);
+            for (int j = 0; j < nk; ++j) {
+                std::vector<double> x = ux, xm = mx, xt, xtm, y, ym, xa(co_n), xam(co_n);
+                const std::string rb = v + "resblocks." + std::to_string(i * nk + j);
+                for (int mth = 0; mth < 3; ++mth) {
+                    for (int q = 0; q < co_n; ++q) {
+                        peak_wc[pass] = std::max(peak_wc[pass], x[q]);           // fp16 operand: leaky_relu(x)
+                        peak_m2[pass] = std::max(peak_m2[pass], xm[q]);
+                        xa[q] = x[q];
+                        xam[q] = 0.505 * xm[q];
+                    }
+                    if (!conv(rb + ".convs1." + std::to_string(mth), xa, xam, xt, xtm)) return false;
+                    for (int q = 0; q < co_n; ++q) {
+                        peak_wc[pass] = std::max(peak_wc[pass], xt[q]);          // fp16 operand: leaky_relu(xt)
+                        peak_m2[pass] = std::max(peak_m2[pass], xtm[q]);
+                        xtm[q] *= 0.505;
+                    }
+                    if (!conv(rb + ".convs2." + std::to_string(mth), xt, xtm, y, ym)) return false;
+                    for (int q = 0; q < co_n; ++q) {
+                        x[q] += y[q];
+                        xm[q] += ym[q];
+                    }
+                }
+                for (int q = 0; q < co_n; ++q) {
+                    us[q] += x[q] / nk;
+                    ms[q] += xm[q] / nk;      // (second moment of a mean of nk terms: at most their mean)
+                }
+            }
+            u.swap(us);
+            m.swap(ms);
+        }
+    }
+    // bound(M) <= const + (at M = 1 minus const) * M: every channel bound is affine in M with non-negative coefficients
+    h->wc_const = peak_wc[0];
+    h->wc_lin = std::max(0.0, peak_wc[1] - peak_wc[0]);
+    h->est_const = std::sqrt(peak_m2[0]);
+    h->est_lin = std::sqrt(std::max(0.0, peak_m2[1] - peak_m2[0]));
+    return true;
+}
+
 int build_vocoder(dtts_ctx* h) {
     Need need{h, ""};
     const dtts_config& c = h->cfg;
@@ -691,6 +808,14 @@ int build_vocoder(dtts_ctx* h) {
         if (!(h->ovf_dev = (unsigned long long*)dev_alloc(h, sizeof(unsigned long long))) || hipMemset(h->ovf_dev, 0, sizeof(unsigned long long)) != hipSuccess)
             return fail(h, DTTS_E_NOMEM, "range-guard counter");
     }
+    if (!h->bad_dev) {
+        if (!(h->bad_dev = (unsigned*)dev_alloc(h, sizeof(unsigned))) || hipMemset(h->bad_dev, 0, sizeof(unsigned)) != hipSuccess)
+            return fail(h, DTTS_E_NOMEM, "overflow-detector counter");
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) != hipSuccess) return fail(h, DTTS_E_NOMEM, "overflow-detector host word");
+        h->bad_host = (volatile unsigned*)hp;
+        *h->bad_host = 0;
+    }
     const int eng = c.vocoder_precision == DTTS_VOC_BF16 ? ENG_BF16 : ENG_BF16X3;                                   // serial convolutions
     const int eng_rb = c.vocoder_precision == DTTS_VOC_F16 ? ENG_F16 : eng;                                         // ResBlock convolutions
     const std::string v = "vocoder.";
@@ -702,7 +827,7 @@ int build_vocoder(dtts_ctx* h) {
         // OPTION (DTTS_TUNE bit 13, off by default): ups.1 — the most expensive serial convolution, 8.4 of their 18.9 MFLOP per frame — in the
         // fp16 two-product form (vconv.hip H2; weights packed as a single fp16 tensor).  Measured: vocoder -0.7 %, pipelined step -0.4 %,
         // waveform RMS error 4.6e-5 -> 7.2e-5 (gate 1e-4): the gain does not pay for a third of the gate's margin, so three products stay.
-        const bool h2 = c.vocoder_precision == DTTS_VOC_F16 && i == 1 && (h->tune & 8192) && (u * (c.upsample_initial_channel >> (i + 1))) % 256 == 0 &&
+        const bool h2 = c.vocoder_precision == DTTS_VOC_F16 && i == 1 && DTTS_TUNE(h, 8192) && (u * (c.upsample_initial_channel >> (i + 1))) % 256 == 0 &&
                         (c.upsample_initial_channel >> i) % 128 == 0;
         ok = ok && pack_transposed(h, need, h->ups[i], h2 ? ENG_F16 : eng, v + "ups." + std::to_string(i), u, (k - u) / 2);
         h->hop *= u;
@@ -728,7 +853,7 @@ int build_vocoder(dtts_ctx* h) {
     for (int i = 0; ok && eng_rb != ENG_BF16X3 && i < c.n_upsamples * nk; ++i) {
         const int j = i % nk, k = c.resblock_kernel_sizes[j];
         const int ch = c.upsample_initial_channel >> (i / nk + 1);
-        if (!rblock_supported(ch, k) || ((h->tune & 8) && ch >= 128)) {   // DTTS_TUNE bit 3: the wide stages' k = 3 ResBlocks per iteration (vpair) again
+        if (!rblock_supported(ch, k) || (DTTS_TUNE(h, 8) && ch >= 128)) {   // DTTS_TUNE bit 3: the wide stages' k = 3 ResBlocks per iteration (vpair) again
             bool vp = h->rb1[i][0].C_in_pad == ch;
             for (int mth = 0; mth < 3; ++mth) vp = vp && vpair_supported(ch, k, c.resblock_dilation_sizes[j][mth]);
             if (eng_rb == ENG_F16 && !vp)
@@ -763,7 +888,7 @@ int build_vocoder(dtts_ctx* h) {
         bool fusable = ok && eng_rb != ENG_BF16X3 && last_ch == 32 && w && w->shape.size() == 3 && w->shape[0] == 1 && w->shape[1] == 32 &&
                        w->shape[2] == 7 && b.size() == 1 && nk >= 2;
         for (int j = 0; fusable && j < nk; ++j) fusable = !h->rbf1[(size_t)(c.n_upsamples - 1) * nk + j].empty();
-        if (fusable && !(h->tune & 1)) {
+        if (fusable && !DTTS_TUNE(h, 1)) {
             std::vector<float> wt((size_t)7 * 32);
             for (int ci = 0; ci < 32; ++ci)
                 for (int k = 0; k < 7; ++k) wt[(size_t)k * 32 + ci] = w->f[(size_t)ci * 7 + k];
@@ -777,6 +902,7 @@ int build_vocoder(dtts_ctx* h) {
         if (h->err.empty()) return fail(h, DTTS_E_NOMEM, "packing / uploading vocoder weights failed");
         return DTTS_E_INVAL;
     }
+    if (c.vocoder_precision == DTTS_VOC_F16 && !vocoder_fp16_analysis(h, need)) return fail(h, DTTS_E_NOENT, "fp16 analysis: missing weight tensor '%s'", need.missing.c_str());
     h->vocoder_ready = true;
     return DTTS_OK;
 }
@@ -1042,12 +1168,12 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
             ch /= 2;
             // (experiment, tune bit 12) C = 32 only: the first TWO ResBlocks in one launch — the k = 3 launch alone is HBM-bound (x in, stage sum out:
             // 4.6 TB/s), together with k = 7 its bytes ride on that launch's compute; the last ResBlock (fused conv_post) stays on its own
-            if (fuse && (h->tune & 4096) && !(h->tune & 512) && nk == 3 && ch == 32 && !h->rbf1[(size_t)i * nk].empty() && !h->rbf1[(size_t)i * nk + 1].empty()) {
+            if (fuse && DTTS_TUNE(h, 4096) && !DTTS_TUNE(h, 512) && nk == 3 && ch == 32 && !h->rbf1[(size_t)i * nk].empty() && !h->rbf1[(size_t)i * nk + 1].empty()) {
                 const int k2 = std::max(h->rbf1[(size_t)i * nk][0].K, h->rbf1[(size_t)i * nk + 1][0].K), TT2 = 1024 - 12 * (k2 - 1);
                 if (TT2 >= 64 && (long long)B * ((rows + TT2 - 1) / TT2) >= 2LL * h->n_cu) fuse_n[i] = 2;
                 continue;
             }
-            bool all = fuse && (h->tune & 512) && nk >= 2 && nk <= 3 && (ch == 32 || ch == 64);
+            bool all = fuse && DTTS_TUNE(h, 512) && nk >= 2 && nk <= 3 && (ch == 32 || ch == 64);
             int kmax = 0;
             for (int j = 0; j < nk && all; ++j) {
                 all = !h->rbf1[(size_t)i * nk + j].empty();
@@ -1083,7 +1209,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
     unsigned* ctrs = A.alloc<unsigned>(N_CTR);
     int n_ctr = 0;
     if (!Xf || !Rf || !Sf || !Rg || !Xa || !Ra || !Ta || !Sa || !melb || !lensS || !ctrs) return fail(h, DTTS_E_NOMEM, "vocoder workspace");
-    const bool dyn_tiles = !(h->tune & 4);   // DTTS_TUNE bit 2: static tile assignment (round 2)
+    const bool dyn_tiles = !DTTS_TUNE(h, 4);   // DTTS_TUNE bit 2: static tile assignment (round 2)
     if (dyn_tiles) HIPCHK(hipMemsetAsync(ctrs, 0, N_CTR * sizeof(unsigned), s));
     {
         StageMult mult;
@@ -1104,7 +1230,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
             delete t;   // closes the span (records the end event)
         }
     } span{h, nullptr};
-    if (h->timers[TV].enabled && !(h->tune & 16)) {
+    if (h->timers[TV].enabled && !DTTS_TUNE(h, 16)) {
         span.t = new Timed(h, TV, s);
         if (span.t->e1) h->timers[TV].launches -= 1;   // (the span itself is not a launch; e1 is null when no event could be created)
         h->voc_span = true;
@@ -1142,7 +1268,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         }
         {   // ups[i] (polyphase): Sa [B,Tcur,2ch] -> Xf / Xa [B,Tcur,u*ch] == [B,Tcur*u,ch]
             VConvParams p = exact ? vparams_x3(h->ups[i], Sf, 2 * ch, 0.1f, lin, B, Tcur) : vparams(h->ups[i], Sa, lin, B, Tcur);
-            p.small_tiles = exact && !(h->tune & 32);   // narrow split-operand upsamplers: 64-row tiles, 4 workgroups / CU (-0.15 ms same-box)
+            p.small_tiles = exact && !DTTS_TUNE(h, 32);   // narrow split-operand upsamplers: 64-row tiles, 4 workgroups / CU (-0.15 ms same-box)
             p.yf = Xf;
             p.ldyf = u * ch;
             p.ya = need_xa ? Xa : nullptr;
@@ -1210,8 +1336,9 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                 rp.el = el;
                 rp.tile_ctr = (dyn_tiles && n_ctr < N_CTR) ? ctrs + n_ctr++ : nullptr;
                 rp.ovf = (exact && h->guard_on) ? h->ovf_dev : nullptr;
-                rp.small_tile = (h->tune & 16384) ? 1 : 0;
-                rp.pingpong = (h->tune & 128) ? 1 : 0;   // tune bit 7: the two-group form of rblock2.hip (experiment)
+                rp.bad = h->bad_dev;
+                rp.small_tile = DTTS_TUNE(h, 16384) ? 1 : 0;
+                rp.pingpong = DTTS_TUNE(h, 128) ? 1 : 0;   // tune bit 7 (-DDTTS_ABLATE builds only): the two-group form of rblock2.hip (experiment)
                 rp.dbg = (g_ablate >> 4) & 15;
                 if (nk == 1) return fail(h, DTTS_E_INVAL, "fused ResBlock path needs >= 2 resblock kernels");
 #ifdef DTTS_ABLATE
@@ -1342,6 +1469,7 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         p.yf = wav;
         p.ldyf = 1;
         p.post_tanh = 1;
+        p.bad = h->bad_dev;
         Timed tm(h, TV, s);
         LAUNCH(vconv_launch(p, s));
     }
@@ -1405,6 +1533,12 @@ void dtts_default_config(dtts_config* c) {
 
 int dtts_create(const dtts_config* cfg, dtts_handle* out) {
     if (!cfg || !out) return fail(nullptr, DTTS_E_INVAL, "dtts_create: null argument");
+    if (cfg->tune_flags & ~TUNE_MASK) {   // (release library: an untested experiment's bit is refused, never silently ignored)
+        char msg[160];
+        snprintf(msg, sizeof msg, "dtts_create: tune_flags 0x%x carries bits this build does not honour (supported mask 0x%x; the others exist only in "
+                 "-DDTTS_ABLATE builds)", (unsigned)cfg->tune_flags, (unsigned)TUNE_MASK);
+        return fail(nullptr, DTTS_E_INVAL, "%s", msg);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, DTTS_E_HIP, "dtts_create: no HIP device visible (the HIP path has no CPU fallback)");
@@ -1439,6 +1573,11 @@ int dtts_create(const dtts_config* cfg, dtts_handle* out) {
 }
 
 void dtts_destroy(dtts_handle h) {
+    if (h && h->bad_host) {
+        (void)hipDeviceSynchronize();
+        (void)hipHostFree((void*)h->bad_host);
+        h->bad_host = nullptr;
+    }
     if (!h) return;
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
@@ -1643,7 +1782,11 @@ int dtts_hifigan_forward(dtts_handle h, const float* mel, const int32_t* lens, i
         if (B > DTTS_MAX_VOCODER_BATCH) return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: B = %d exceeds %d utterances per call", B, DTTS_MAX_VOCODER_BATCH);
         if (c.vocoder_precision == DTTS_VOC_F16 && ((uintptr_t)mel & 15))
             return fail(h, DTTS_E_INVAL, "dtts_hifigan_forward: DTTS_VOC_F16 reads mel with 16-byte loads: the pointer must be 16-byte aligned");
-        return hifigan_forward_fused(h, mel, lens, B, T, wav, s);
+        const int rc = hifigan_forward_fused(h, mel, lens, B, T, wav, s);
+        // the detector's count follows the forward's last kernel into pinned host memory: whoever synchronises with this stream to read the
+        // waveform can read it (dtts_vocoder_nonfinite) without another synchronisation
+        if (rc == DTTS_OK && h->bad_dev && h->bad_host) HIPCHK(hipMemcpyAsync((void*)h->bad_host, h->bad_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        return rc;
     }
     // largest activation: stage i has T*prod(u[:i+1]) rows of C0/2^(i+1) channels
     size_t max_elems = (size_t)B * T * c.upsample_initial_channel;
@@ -1974,7 +2117,7 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
     // (dict_encoder.py:36-39: the reference projects every gloss row of every batch; here once, at upload) — 2 x hidden_size floats per
     // row instead of 768 (+ 768), and the logit becomes k . q in the reference's own association order.  tune bit 64 keeps the raw
     // rows (round 2's table: the re-associated kernel of the tensor API reads them).
-    const bool projected = !(h->tune & 64);
+    const bool projected = !DTTS_TUNE(h, 64);
     if (projected && !h->acoustic_ready)
         return fail(h, DTTS_E_STATE, "dtts_dict_table_upload: the acoustic weights must be finalized first (the table stores k_transform / v_transform projections)");
     if (projected && nL > (size_t)INT_MAX / 2) return fail(h, DTTS_E_INVAL, "dtts_dict_table_upload: %zu gloss rows", nL);
@@ -2029,7 +2172,10 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off,
                     what ? what : "device allocation", hipGetErrorString(herr), h->t_entries ? "; the previous table stays in use" : "");
     }
     if (h->t_entries) {   // a second upload replaces the table: release the previous one (nothing may still be using it)
-        HIPCHK(hipDeviceSynchronize());
+        if ((herr = hipDeviceSynchronize()) != hipSuccess) {   // (the new table is released again; the previous one stays in use)
+            for (void* q : fresh) dev_free(h, q);
+            return fail(h, DTTS_E_HIP, "dtts_dict_table_upload: hipDeviceSynchronize failed (%s); the previous table stays in use", hipGetErrorString(herr));
+        }
         void* old[] = {h->t_off, h->t_poff, h->t_pmmax, h->t_keys, h->t_values != h->t_keys ? h->t_values : nullptr, h->t_key_map, h->t_pinyin, h->t_pinyin_map};
         for (void* q : old) dev_free(h, q);
     }
@@ -2294,6 +2440,22 @@ int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream s
     if (reset) HIPCHK(hipMemsetAsync(h->ovf_dev, 0, sizeof v, s));
     HIPCHK(hipStreamSynchronize(s));
     *count = (int64_t)v;
+    return DTTS_OK;
+}
+
+int dtts_vocoder_nonfinite(dtts_handle h, int64_t* count) {
+    if (!h || !count) return DTTS_E_INVAL;
+    if (!h->vocoder_ready) return fail(h, DTTS_E_STATE, "vocoder weights not finalized");
+    *count = h->bad_host ? (int64_t)*h->bad_host : 0;
+    return DTTS_OK;
+}
+
+int dtts_vocoder_fp16_bound(dtts_handle h, float mel_abs_max, double* worst_case, double* rms_estimate) {
+    if (!h || !(mel_abs_max >= 0.f)) return DTTS_E_INVAL;
+    if (!h->vocoder_ready) return fail(h, DTTS_E_STATE, "vocoder weights not finalized");
+    const bool f16 = h->cfg.vocoder_precision == DTTS_VOC_F16;
+    if (worst_case) *worst_case = f16 ? h->wc_const + h->wc_lin * (double)mel_abs_max : 0.0;
+    if (rms_estimate) *rms_estimate = f16 ? std::sqrt(h->est_const * h->est_const + h->est_lin * h->est_lin * (double)mel_abs_max * mel_abs_max) : 0.0;
     return DTTS_OK;
 }
 

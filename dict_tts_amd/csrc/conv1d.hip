@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvParams p) {
 #endif
 #if C1D_PROF
 __device__ unsigned long long c1d_prof[4][2048][8];
-extern "C" int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(c1d_prof), sizeof(c1d_prof)); }
+extern "C" __attribute__((visibility("default"))) int dtts_debug_c1d_prof(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(c1d_prof), sizeof(c1d_prof)); }
 #define STAMP(i) if (pslot >= 0 && threadIdx.x == 0) { c1d_prof[pslot][pwg][i] = __builtin_readcyclecounter(); }
 #else
 #define STAMP(i)

@@ -84,9 +84,13 @@ __device__ __forceinline__ uint2 act4(const f32x4& v, float slope) {
 #else
         // convert first, then leaky_relu on PACKED fp16 pairs: v_cvt_pk_f16_f32, v_pk_mul_f16, v_pk_max_f16 = 6 VALU per 4 values (the
         // activation rewrites of the narrow ResBlock kernels are VALU-bound, LABNOTES round 4 (C)).  The slope is fp16(0.1) and negative
-        // values round twice: simulated waveform error 5.19e-5 -> 5.28e-5 (tools/precision_sim.py arithmetic).  No saturation: a
-        // pre-activation beyond the fp16 range becomes +-inf — exactly what the range guard (ovf4 below, on the fp32 values) counts.
-        const f16x2_t slope2 = {(_Float16)0.1f, (_Float16)0.1f};
+        // values round twice: simulated waveform error 5.19e-5 -> 5.28e-5 (tools/precision_sim.py arithmetic).  NO saturation, on purpose: a
+        // pre-activation beyond the fp16 range becomes +-inf (also a NEGATIVE one below -65504, whose exact leaky_relu would still be
+        // representable), the inf / NaN it makes of every later sum reaches conv_post, and the always-on detector there (rblock.hip /
+        // vconv.hip: non-finite pre-tanh value) reports the call — no overflow returns plausible-looking samples.  ovf4 below counts
+        // exactly these values.
+        const _Float16 hs = (_Float16)slope;   // (a compile-time constant at every call site: folds)
+        const f16x2_t slope2 = {hs, hs};
         const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
         const f16x2_t ra = __builtin_elementwise_max(ha, ha * slope2), rb = __builtin_elementwise_max(hb, hb * slope2);
         (void)ta;
@@ -104,13 +108,20 @@ __device__ __forceinline__ uint2 act4(const f32x4& v, float slope) {
 }
 
 // fp16 range guard (GUARD instantiations of vpair / rblock, DTTS_VOC_F16 only): how many of four pre-activation values the 16-bit
-// conversion cannot represent — leaky_relu(v) > 65504 saturates (v_med3 above), v * slope < -65504 overflows to -inf.  The reference
-// computes these convolutions in fp32 (modules/hifigan/hifigan.py:51-58): a non-zero count means the fp16 mode is not valid for this
-// checkpoint / input, and the caller falls back to DTTS_VOC_BF16X3 (dict_tts_amd/vocoder.py).
+// conversion of act4 turns into +-inf — the conversion comes FIRST there, so |v| > 65504 overflows on either side (round 3's form,
+// -DDTTS_ACT_F32, applied leaky_relu in fp32 first: v > 65504 saturated, v * slope < -65504 overflowed).  The reference computes these
+// convolutions in fp32 (modules/hifigan/hifigan.py:51-58): a non-zero count means the fp16 mode is not valid for this checkpoint /
+// input, and the caller falls back to DTTS_VOC_BF16X3 (dict_tts_amd/vocoder.py).
 __device__ __forceinline__ int ovf4(const f32x4& v, float slope) {
     int n = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) n += (v[e] > 65504.f || v[e] * slope < -65504.f) ? 1 : 0;
+    for (int e = 0; e < 4; ++e) {
+#ifdef DTTS_ACT_F32
+        n += (v[e] > 65504.f || v[e] * slope < -65504.f) ? 1 : 0;
+#else
+        n += (__builtin_fabsf(v[e]) > 65504.f) ? 1 : 0;
+#endif
+    }
     return n;
 }
 

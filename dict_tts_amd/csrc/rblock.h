@@ -36,6 +36,7 @@ struct RBlockParams {
     int el;                // 16-bit operand type: EL_BF16 (rb_common.h) or EL_F16; the packed weights are in that type
     unsigned* tile_ctr;    // persistent configurations: device counter (zero at launch) for dynamic tile claiming, or null = static w, w + G, ...
     int pre_off;           // (set by the launcher) byte offset of the tile-count table in dynamic LDS
+    unsigned* bad;         // always-on detector of the fused conv_post: device counter of NON-FINITE pre-tanh values (an fp16 operand overflowed upstream), or null
     unsigned long long* ovf;   // fp16 range guard: device counter of unrepresentable activations (launches the GUARD instantiation), or null
     int small_tile;        // tune bit 14: C = 64 keeps 512-row tiles at k >= 7 (A/B against the default 640)
     int pingpong;          // 1: the phase-shifted two-group form (rblock2.hip; an experiment, dtts_config.tune_flags bit 7)

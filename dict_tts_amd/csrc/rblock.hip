@@ -437,7 +437,15 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             a += __shfl_xor(a, 2, 64);
             a += __shfl_xor(a, 4, 64);
             const int t = t0 + PH + o;
-            if (q8 == 0 && o < TTo && t < len) wb[t] = tanhf(a + pb);
+            // ALWAYS-ON overflow detector (every instantiation, every call): an fp16 operand that overflowed anywhere upstream is +-inf, every
+            // sum it enters is inf / NaN from there on (the fp32 residual stream never recovers), so it arrives HERE as a non-finite
+            // pre-tanh value.  tanh would turn +-inf into a plausible +-1: the sample is poisoned with NaN instead and counted.
+            const float pre = a + pb;
+            const bool nonfin = !(__builtin_fabsf(pre) <= 3.0e38f);
+            if (q8 == 0 && o < TTo && t < len) {
+                wb[t] = nonfin ? __builtin_nanf("") : tanhf(pre);
+                if (nonfin && p.bad) atomicAdd(p.bad, 1u);   // (never on a healthy call)
+            }
         }
     }
     }   // (epilogue)
@@ -563,7 +571,17 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
         return hipErrorInvalidValue;
     }
     // (experiment, tune bit 7) C = 32 without the fused conv_post: two phase-shifted groups per workgroup (rblock2.hip)
+#ifdef DTTS_ABLATE   // (rblock2.hip is compiled into the ablation library only)
     if (p.pingpong && rblock2_supported(C, p.K, p.wav != nullptr) && !few(512)) return rblock2_launch(p, C, stream);
+#endif
+#if defined(RB_X32) && RB_X32 == 1   // experiment: 12 waves (3 per SIMD) over 1152 rows at C = 32, k >= 7
+    if (C == 32 && rb32 && p.K >= 7 && !few(1152)) {   // (with the fused conv_post the 1152-row output tile does not fit the LDS: falls through)
+        const hipError_t e = rb_launch_cfg<32, 3, 1, 12, 1, EL, 1>(p, stream);
+        if (e != hipErrorInvalidValue) return e;
+    }
+#elif defined(RB_X32) && RB_X32 == 2 // experiment: 12 waves (3 per SIMD) over 768 rows, MT = 2
+    if (C == 32 && rb32 && p.K >= 7 && !few(768)) return rb_launch_cfg<32, 2, 1, 12, 1, EL, 1>(p, stream);
+#endif
     if (C == 32 && rb32 && p.K >= 7 && !few(1024)) return rb_launch_cfg<32, 4, 1, 8, 1, EL, 1>(p, stream);
     if (C == 64 && few(512)) return rb_launch_cfg<64, 4, 1, 2, 2, EL, 1>(p, stream);     // 256-row tile, 4 waves
     if (C == 128 && few(256)) return rb_launch_cfg<128, 4, 1, 1, 4, EL, 1>(p, stream);   // 128-row tile, 4 waves
@@ -571,6 +589,14 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
     if (C == 32) return rb_launch_cfg<32, 4, 1, 4, 1, EL, 0>(p, stream);      // 512-row tile, 4 waves over time
     // C = 64, k >= 7: 640-row tiles (MT = 5; the halo 12 (k - 1) is 11 / 19 % of the tile instead of 14 / 23 %: -4.8 % at k = 11, nothing at k = 3
     // where 13 spilled registers cost what the halo gives); tune bit 14: 512-row tiles for every k (round 3)
+#if defined(RB_X64) && RB_X64 <= 2   // experiment: 12 waves (3 per SIMD: 6 time x 2 channel), 576-row tiles, 168 registers: RB_X64 = 1 for k >= 7, 2 for every k
+    if (C == 64 && (p.K >= 7 || RB_X64 >= 2) && !p.small_tile) return rb_launch_cfg<64, 3, 1, 6, 2, EL, 1>(p, stream);
+#elif defined(RB_X64)                // experiment: 16 waves (4 per SIMD: 8 time x 2 channel), 512-row tiles, 128 registers, every k
+    if (C == 64 && !p.small_tile) return rb_launch_cfg<64, 2, 1, 8, 2, EL, 1>(p, stream);
+#endif
+#if defined(RB_X128)  // experiment: 12 waves (3 time x 4 channel), 288-row tiles at C = 128 (k = 3)
+    if (C == 128) return rb_launch_cfg<128, 3, 1, 3, 4, EL, 1>(p, stream);
+#endif
     if (C == 64 && p.K >= 7 && !p.small_tile) return rb_launch_cfg<64, 5, 1, 4, 2, EL, 1>(p, stream);
     if (C == 64) return rb_launch_cfg<64, 4, 1, 4, 2, EL, 1>(p, stream);      // 512-row tile, 8 waves (4 time x 2 channel)
     if (C == 128) return rb_launch_cfg<128, 4, 1, 2, 4, EL, 1>(p, stream);    // 256-row tile, 8 waves (2 time x 4 channel)

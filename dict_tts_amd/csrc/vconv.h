@@ -45,6 +45,7 @@ struct VConvParams {
     int poly_half;            // PackedConv::poly_half: waves in the first half of the packed channels skip the last tap, the others the first
     float div;                // 1 or num_kernels (true division)
     int post_tanh;
+    unsigned* bad;            // with post_tanh: device counter of non-finite pre-tanh values (the always-on overflow detector), or null
     int dbg;                  // -DDTTS_ABLATE builds only (DTTS_VCONV_DBG): 1 = skip the contraction, 2 = skip the epilogue, 4 = skip staging
 };
 

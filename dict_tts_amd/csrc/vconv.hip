@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 :
     const int wt = wave % WT, wc = wave / WT;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * TT;
-    const int len = p.lens ? p.lens[b] : p.T;
+    const int len = __builtin_amdgcn_readfirstlane(p.lens ? p.lens[b] : p.T);   // (uniform: it sizes a buffer resource)
     if (t0 >= len) return;
     const int ct0 = blockIdx.y * (CO_T / 32) + wc * NT;
     const int NCT = p.C_out_pad >> 5;
@@ -123,29 +123,37 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 :
     for (int ci0 = 0; ci0 < p.C_in_pad; ci0 += CK) {
         if (ci0) __syncthreads();
         if constexpr (X3) {   // fp32 in: leaky_relu, bf16 hi / lo split, two LDS tiles; 4 channels per 16 B load
-            constexpr int U = 4, PIECES = CK / 4;
-            const int total = rows * PIECES;
-            for (int base = tid; base < total; base += 256 * U) {
-                f32x4 v[U];
+#ifndef VC_U_SMALL
+#define VC_U_SMALL 4
+#endif
+            // A thread keeps its 4-channel piece and walks the rows in steps of 256 / PIECES.  Buffer loads over the utterance's rows
+            // [0, len): a row outside it (t < 0 wraps to a huge unsigned offset, t >= len exceeds num_records) returns zeros = the zero
+            // padding, no per-access compare, one VGPR of address per load.  U loads in flight per thread and batch: the narrow 64-row
+            // upsampler tiles (8-9 pieces per thread) take ONE batch = one exposed HBM round trip per tile instead of three.
+            constexpr int U = MT <= 2 ? VC_U_SMALL : 4, PIECES = CK / 4, RS = 256 / PIECES;
+            static_assert(256 % PIECES == 0, "a thread keeps its column");
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xfb, 0, len * p.ldx * 4, 0x00020000);
+            const int c = tid % PIECES, r0 = tid / PIECES;
+            const bool c_ok = ci0 + c * 4 < p.C_in;
+            const int voff0 = ((in0 + r0) * p.ldx + ci0 + c * 4) * 4, vstep = RS * p.ldx * 4;
+            const int nk = (rows - r0 + RS - 1) / RS;   // rows this thread stages
+            for (int kb = 0; kb < nk; kb += U) {
+                u32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (c_ok && kb + u < nk) ? voff0 + (kb + u) * vstep : (int)0x80000000, 0, 0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int idx = base + u * 256;
-                    const int r = idx / PIECES, c = idx % PIECES;
-                    const int t = in0 + r;
-                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (idx < total && t >= 0 && t < len && ci0 + c * 4 < p.C_in) v[u] = *(const f32x4*)(xfb + (long long)t * p.ldx + ci0 + c * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = base + u * 256;
-                    const int r = idx / PIECES, c = idx % PIECES;
-                    if (idx >= total) continue;
+                    if (kb + u >= nk) continue;
+                    const int r = r0 + (kb + u) * RS;
+                    const f32x4 vf = __builtin_bit_cast(f32x4, v[u]);
                     float a[4], lo[4];
                     unsigned hb[4];
                     if constexpr (H2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            a[e] = lrelu(v[u][e], p.in_slope);
+                            a[e] = lrelu(vf[e], p.in_slope);
                             const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);   // saturate: lo carries the rest
                             hb[e] = (unsigned)__builtin_bit_cast(unsigned short, hh);
                             lo[e] = a[e] - (float)hh;
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 :
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        a[e] = lrelu(v[u][e], p.in_slope);
+                        a[e] = lrelu(vf[e], p.in_slope);
                         hb[e] = rf2bf(a[e]);
                         lo[e] = a[e] - __builtin_bit_cast(float, hb[e] << 16);
                     }
@@ -411,7 +419,11 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 :
                     if (p.res) u += p.res[row * p.ldres + co + e];
                     if (p.res2) u += p.res2[row * p.ldres2 + co + e];
                     if (p.div != 1.f) u = u / p.div;
-                    if (p.post_tanh) u = tanhf(u);
+                    if (p.post_tanh) {   // (+ the always-on overflow detector, as in rblock.hip's fused conv_post)
+                        const bool nonfin = !(__builtin_fabsf(u) <= 3.0e38f);
+                        if (nonfin && p.bad) atomicAdd(p.bad, 1u);
+                        u = nonfin ? __builtin_nanf("") : tanhf(u);
+                    }
                     if (p.yf) p.yf[row * p.ldyf + co + e] = u;
                     if (p.ya) p.ya[row * p.ldya + co + e] = (unsigned short)vf2bf(u > 0.f ? u : u * p.slope);
                 }

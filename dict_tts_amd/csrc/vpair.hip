@@ -21,14 +21,17 @@ namespace dtts {
 // TT = 128: 3 workgroups per CU; TT = 256: every weight fragment feeds 8 MFMAs instead of 4 (half the weight stream
 // through the texture path, half the halo), 2 workgroups per CU when the LDS tile allows
 // C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
-template <int C, int TT, int EL, bool GUARD>
-__global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_kernel(const VPairParams p) {
-    constexpr bool PS = !(C == 128 && TT == 128);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
+// WT = 2 (C = 128): the four waves as 2 (time) x 2 (output channels), two co-tiles per wave — every activation fragment read from LDS feeds two
+// MFMAs instead of one (half the ds_read_b128 traffic; twice the weight fragments through the texture path, as at C = 256).
+template <int C, int TT, int EL, bool GUARD, int WT = 1>
+__global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) void vpair_kernel(const VPairParams p) {
+    constexpr bool PS = !(C == 128 && TT == 128 && WT == 1);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = (TT == 192 || TT == 96) ? 3 : (TT == 64 ? 2 : 4), NT = C / 128, MH = TT / (32 * MT), MTT = MT * MH;   // TT = 192: two passes of 3 row tiles
+    constexpr int WC = 4 / WT, TW = TT / WT;     // waves over the output channels; rows of a time-wave
+    constexpr int MT = (TW == 192 || TW == 96) ? 3 : (TW == 64 ? 2 : 4), NT = C / (32 * WC), MH = TW / (32 * MT), MTT = MT * MH;   // TW = 192: two passes of 3 row tiles
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
     constexpr int EP = C * 4 + 16, F4 = C / 4;
-    static_assert(NCT == 4 * NT && (NT == 1 || MH == 1), "4 waves over the output channels");
+    static_assert(NCT == WC * NT && (NT == 1 || MH == 1) && WT * WC == 4, "4 waves: WT over time x WC over the output channels");
     const int tid0 = threadIdx.x;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = TT - 2 * h2;             // valid output rows per tile
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     // VALU instructions — instead of being hoisted out of the tile loop by hipcc and spilled to scratch for lack of registers)
     int tid = tid0;
     if constexpr (PS) asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv / WT, wt = wv % WT;
     int len, t0;
     if constexpr (PS) {
         while (pre[b + 1] <= j) ++b;             // the utterance index only moves forward
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
             for (int q = 0; q < 4; ++q) bb[n][q] = *(const f32x4*)(p.b2 + (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5));
     };
     if (NT == 1) load_b2();   // lands while c1 runs; at C = 256 its 32 registers do not fit beside c1's (spills): fetched after c1 there
-    const int xlane = (lane & 31) * PITCH + (lane >> 5) * 16;
+    const int xlane = (wt * TW + (lane & 31)) * PITCH + (lane >> 5) * 16;
     rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     if (NT != 1) load_b2();
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     // ---- bf16(leaky_relu(xt)) overwrites it (rows 0..127), zero outside the utterance
 #pragma unroll
     for (int m = 0; m < (DTTS_DBG(p, 8) ? 0 : MTT); ++m) {
-        const int r = m * 32 + (lane & 31);
+        const int r = wt * TW + m * 32 + (lane & 31);
         const int t = t0 - h2 + r;
         const bool inb = t >= 0 && t < len;
 #pragma unroll
@@ -201,14 +205,15 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
     // ---- epilogue: 32-row slabs through LDS, whole rows out; residual x re-read (L2), xs accumulated per mode.
     // Buffer loads / stores again: rows >= len are dropped by the range check, the garbage rows o >= TTe of the last
     // slab are sent out of range explicitly.  The reads of slab m+1 are issued before slab m is processed.
-    constexpr int PER = 32 * F4 / 256;
+    constexpr int PER = WT * 32 * F4 / 256;     // a pass moves one 32-row slab of every time-wave
     float* yu = p.y + brow * C;
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, len * C * 4, 0x00020000);
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ya ? p.ya + brow * C : (unsigned short*)yu), 0, len * C * 2, 0x00020000);
-    const int eoff0 = ((t0 + r0) * C + c4 * 4) * 4;
+    const int eoff0 = (t0 * C + c4 * 4) * 4;
     auto eoff = [&](int m, int u) {                 // byte offset of (slab m, access u) or out of range
-        const int o = m * 32 + u * RSTEP + r0;
-        return o < TTe ? eoff0 + (m * 32 + u * RSTEP) * (C * 4) : (int)0x80000000;
+        const int sr = u * RSTEP + r0;              // staged row: slab m of time-wave sr / 32
+        const int o = (sr >> 5) * TW + m * 32 + (sr & 31);
+        return o < TTe ? eoff0 + o * (C * 4) : (int)0x80000000;
     };
     constexpr int EB = NT == 1 ? 2 : 1;   // slab reads double-buffered only while the registers allow it
     u32x4 xin[EB][PER], sold[EB][PER];
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128) ? 3 : 2) void vpair_ke
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e];
-                *(f32x4*)(smem + (lane & 31) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
+                *(f32x4*)(smem + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
             }
         if (EB == 2 && m + 1 < MTT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
         __syncthreads();
@@ -275,7 +280,7 @@ bool vpair_supported(int C, int K, int dil) {
     return (C == 128 || C == 256) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
 }
 
-template <int CC, int TT, int EL, bool GUARD = false>
+template <int CC, int TT, int EL, bool GUARD = false, int WT = 1>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
@@ -286,17 +291,17 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     size_t rows = (size_t)TT + 2 * h1 + std::max(p.dil + 1, RSTEP);
     if (rows < (size_t)TT + p.K + 1) rows = TT + p.K + 1;
     size_t lds = rows * PITCH;
-    const size_t ep = (size_t)32 * (CC * 4 + 16);
+    const size_t ep = (size_t)WT * 32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
     VPairParams q = p;
     q.pre_off = (int)lds;                          // tile table: prefix sums [B + 1], counts [B], lengths [B]
-    constexpr bool PS = !(CC == 128 && TT == 128);
+    constexpr bool PS = !(CC == 128 && TT == 128 && WT == 1);
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if constexpr (EL == EL_F16 && !GUARD) {
-        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true>(p, stream);
+        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, WT>(p, stream);
     }
-    auto kern = vpair_kernel<CC, TT, EL, GUARD>;
+    auto kern = vpair_kernel<CC, TT, EL, GUARD, WT>;
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;
@@ -319,7 +324,7 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
         if (hipGetDeviceProperties(&prop, cur_dev) != hipSuccess) return hipErrorInvalidDevice;
         cus = prop.multiProcessorCount;
     }
-    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), (CC == 128 && TT == 128) ? 3 : 2));
+    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), (CC == 128 && TT == 128 && WT == 1) ? 3 : 2));
     const long long max_tiles = (long long)p.B * ((p.T + TTe - 1) / TTe);
     const int grid = (int)std::min<long long>((long long)cus * per_cu, max_tiles);
     if (grid <= 0) return hipSuccess;
@@ -361,6 +366,10 @@ static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t strea
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
     const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
     if (small_ok && 2 * tiles_of(256) <= vpair_cus()) return vpair_launch_tt<128, 128, EL>(p, stream);
+#ifdef VP_NT2   // experiment: 2 x 2 waves, two co-tiles per wave
+    if (big) return vpair_launch_tt<128, 256, EL, false, 2>(p, stream);
+    return vpair_launch_tt<128, 192, EL, false, 2>(p, stream);
+#endif
     if (big) return vpair_launch_tt<128, 256, EL>(p, stream);
     // k = 11 with dilation 5: 192-row tiles (two workgroups per CU, persistent) instead of 128-row ones (three, one tile each)
     return vpair_launch_tt<128, 192, EL>(p, stream);

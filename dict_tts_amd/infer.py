@@ -40,7 +40,7 @@ def infer_batch(model, vocoder, batch, z_p=None):
     pinyin_map, pron_modified).  Returns (outputs dict, list of float32 waveforms, one per utterance)."""
     out = _model_forward(model, batch, z_p)
     lens = out["mel_lens"]
-    wav = vocoder.forward_batch(out["mel_out"], lens)
+    wav = vocoder.forward_batch(out["mel_out"], lens, check=True) if hasattr(vocoder, "overflowed") else vocoder.forward_batch(out["mel_out"], lens)
     hop = vocoder.hop
     lens_h = lens.cpu().tolist()
     wav_h = wav.cpu().numpy()
@@ -67,9 +67,21 @@ def _iter_results(model, vocoder, batches, pipeline, out_wav_norm=False):
     int16_on_device = hasattr(vocoder, "to_int16")
     hop = vocoder.hop
 
+    st = {"redo_next": False}
+
     def finish(p):
         batch, out, wav, done = p
         done.synchronize()
+        if hasattr(vocoder, "overflowed"):
+            # the always-on detector (dict_tts_amd/vocoder.py): an fp16 operand overflowed in this batch — or in the previous one, in
+            # which case this batch was already in flight in fp16 and is redone too.  check=True redoes in DTTS_VOC_BF16X3 (AUTO) or raises.
+            bad = vocoder.overflowed()
+            need, st["redo_next"] = bad or st["redo_next"], bad
+            if need:
+                with torch.cuda.stream(voc_stream):
+                    wav = vocoder.forward_batch(out["mel_out"], out["mel_lens"], check=True)
+                    if int16_on_device:
+                        wav = vocoder.to_int16(wav, out["mel_lens"], norm=out_wav_norm)
         with torch.cuda.stream(voc_stream):
             wav_h = wav.cpu().numpy()          # int16 when the vocoder converts on the device (half the copy)
         lens_h = out["mel_lens"].cpu().tolist()

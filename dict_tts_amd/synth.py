@@ -225,6 +225,19 @@ def zh_dict_struct():
 BOS_ID, EOS_ID = 1203, 1204  # any ids >= 3 outside the char range; '<BOS>'/'<EOS>' are ordinary vocabulary words
 
 
+def config5_sentences(n=128, seed=55, entries=None):
+    """BASELINE.json configs[4] / SURVEY §8d 'Config 5': n mixed-length utterances, T_w ~ U{6..60} characters drawn from the WHOLE
+    dictionary with the heteronyms (>= 2 pronunciations) over-sampled x5; the first / last table rows appear.  -> list of id lists"""
+    ent = entries if entries is not None else zh_dict_struct()["entries"]
+    rng = np.random.default_rng(seed)
+    ids = np.array(sorted(ent))
+    wts = np.array([5.0 if len(ent[i]) > 1 else 1.0 for i in ids])
+    wts /= wts.sum()
+    sents = [rng.choice(ids, size=int(rng.integers(6, 61)), p=wts).tolist() for _ in range(n)]
+    sents[0][0], sents[1][-1] = int(ids[0]), int(ids[-1])
+    return sents
+
+
 def dict_entry(word_id, seed=1234, entries=None):
     """One ``dict_embed`` item (binarizer_zh.py:301-309): key/value [L,768] (same content), key_map [L],
     pinyin [P], pinyin_map [P]."""

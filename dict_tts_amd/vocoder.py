@@ -61,17 +61,25 @@ def find_vocoder_checkpoint(base_dir):
 class HifiGAN:
     """Same contract as the reference class: ``spec2wav(mel[T,80], **ignored) -> np.float32[T*hop]``."""
 
-    GUARD_CALLS = 4    # precision not chosen explicitly: the first calls run with the fp16 range guard on ...
-    GUARD_EVERY = 16   # ... and afterwards every GUARD_EVERY-th call does (overflow depends on the input, not only on the checkpoint)
+    FP16_MAX = 65504.0
+    MEL_ABS_MAX = 6.0     # the reference's log10-mel lies in [-6, 1.5] (egs/egs_bases/tts/base.yaml:59-60): range of the static bound
+    EST_SIGMAS = 16.0     # an RMS estimate within FP16_MAX / EST_SIGMAS of the limit: do not even try fp16
 
     def __init__(self, state_dict=None, config=None, precision=None, ctx=None, unfused=False, range_guard=None):
-        """precision: None (= env DTTS_VOCODER_PRECISION, else AUTO) | 'f16' | 'bf16' | 'bf16x3' | abi.VOC_*.
-        AUTO = DTTS_VOC_F16 (the waveform-exact default) with two safety nets, because fp16 operands have a narrower range than
-        the reference's fp32 arithmetic: (1) a generator shape the fused fp16 kernels do not cover falls back to DTTS_VOC_BF16X3
-        at construction; (2) the first GUARD_CALLS forward calls, and every GUARD_EVERY-th call after them, run with the library's
-        range guard on (dtts_vocoder_range_guard; a guarded call synchronises its stream to read the count) and a call that
-        saturated / overflowed an fp16 activation is REDONE in DTTS_VOC_BF16X3, which the object then keeps.
-        An explicit precision is taken literally; range_guard=True then keeps the guard on for every call and raises on a clamp."""
+        """precision: None (AUTO) | 'f16' | 'bf16' | 'bf16x3' | abi.VOC_*.  Nothing is read from the process environment.
+
+        fp16 operands have a narrower range than the reference's fp32 arithmetic (modules/hifigan/hifigan.py:51-58).  Whether
+        DTTS_VOC_F16 is valid is DECIDED, not sampled (include/dicttts_hip.h: dtts_vocoder_fp16_bound / dtts_vocoder_nonfinite):
+          * at construction, from the folded weights: ``fp16_status`` is 'proven' (worst-case bound of every fp16 operand < 65504 for
+            |mel| <= MEL_ABS_MAX: no call in that range can overflow), 'checked' (not provable — every trained generator — fp16 under
+            the always-on detector) or, AUTO only, 'rejected' (the propagated RMS estimate already nears the fp16 limit, or the fused
+            kernels do not cover the generator's shape: DTTS_VOC_BF16X3 from the start);
+          * on EVERY call, by the conv_post epilogue's detector: a forward in which any fp16 operand overflowed delivers non-finite
+            pre-tanh values, which are counted and poisoned with NaN.  spec2wav / spec2wav_batch / forward_batch(check=True) read the
+            count behind their synchronisation: AUTO redoes the call in DTTS_VOC_BF16X3 and keeps that mode, an explicit 'f16' raises.
+            A pipelined caller (forward_batch without check) calls ``overflowed()`` after it has synchronised for the waveform.
+        No call can return garbage silently.  range_guard=True additionally runs the CENSUS instantiations on every call (all 72
+        conversion points counted, a few % slower) and raises on a clamp: the parity tests' mode."""
         if state_dict is None:
             config, state_dict = find_vocoder_checkpoint(hparams_mod.hparams["vocoder_ckpt"])   # looked up at call time: the
             # INTEGRATION.md hook may rebind dict_tts_amd.hparams.hparams after this module was imported
@@ -79,40 +87,49 @@ class HifiGAN:
         if not torch.cuda.is_available():
             raise abi.DttsError("dict_tts_amd.vocoder.HifiGAN needs a ROCm GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
-        if precision is None and os.environ.get("DTTS_VOCODER_PRECISION"):
-            precision = os.environ["DTTS_VOCODER_PRECISION"]
         auto = precision is None
         if auto:
             precision = abi.VOC_F16   # the waveform-exact default
         elif isinstance(precision, str):
             precision = abi.VOC_PRECISIONS[precision]
         self._unfused = unfused
-        self._guard_left = 0      # -1: every call guarded (range_guard=True); > 0: the initial guarded calls left; 0 + _auto_guard: sampled
-        self._guard_raise = False
-        self._auto_guard = False
-        self._calls = 0
-        self._state_dict = None
+        self._auto = auto
+        self._census = False      # range_guard=True: the census instantiations on every call, a clamp raises
+        self._state_dict = None   # AUTO in fp16: kept for the fallback (host tensors the caller handed over)
+        self._seen_bad = 0
+        self.fp16_status = None   # 'proven' | 'checked' | 'rejected' | None (not an fp16 mode)
+        self.fp16_bound = None    # (worst_case, rms_estimate) at MEL_ABS_MAX
         if ctx is not None:
             self.precision = precision
             self.ctx = ctx
             self.ctx.load_state_dict("vocoder", state_dict)
             self.ctx.finalize(abi.PART_VOCODER)
         else:
-            guard = precision == abi.VOC_F16 and (auto or bool(range_guard))
+            census = precision == abi.VOC_F16 and bool(range_guard)
             try:
-                self._build(state_dict, precision, guard)
+                self._build(state_dict, precision, census)
             except abi.DttsError as e:
                 if not (auto and "DTTS_VOC_BF16X3" in str(e)):
                     raise
                 import warnings
                 warnings.warn(f"HifiGAN: the fused fp16 kernels do not cover this generator ({e}); using DTTS_VOC_BF16X3")
                 self._build(state_dict, abi.VOC_BF16X3, False)
-                guard = False
-            if guard:
-                self._guard_left = -1 if range_guard else self.GUARD_CALLS
-                self._guard_raise = bool(range_guard) and not auto
-                self._auto_guard = auto
-                self._state_dict = state_dict if auto else None   # kept for the fallback (host tensors the caller handed over)
+                self.fp16_status = "rejected"
+                census = False
+            self._census = census
+        if self.precision == abi.VOC_F16:
+            wc, est = self.ctx.vocoder_fp16_bound(self.MEL_ABS_MAX)
+            self.fp16_bound = (wc, est)
+            self.fp16_status = "proven" if wc < self.FP16_MAX else "checked"
+            if auto and ctx is None and est * self.EST_SIGMAS > self.FP16_MAX:
+                import warnings
+                warnings.warn(f"HifiGAN: the propagated RMS of an fp16 operand is {est:.3g} (limit {self.FP16_MAX:.0f}): "
+                              f"DTTS_VOC_F16 is not valid for this checkpoint, using DTTS_VOC_BF16X3")
+                self._build(state_dict, abi.VOC_BF16X3, False)
+                self.fp16_status = "rejected"
+            elif auto and ctx is None:
+                self._state_dict = state_dict
+            self._seen_bad = self.ctx.vocoder_nonfinite()
         self.hop = self.ctx.hop()
 
     def _build(self, state_dict, precision, guard):
@@ -123,16 +140,28 @@ class HifiGAN:
         ctx.load_state_dict("vocoder", state_dict)
         ctx.finalize(abi.PART_VOCODER)
         self.ctx, self.precision = ctx, precision
+        self._seen_bad = 0   # (a new context counts from zero)
 
     # -- reference API -------------------------------------------------------------------------------------
     def spec2wav(self, mel, **kwargs):
         """vocoders/hifigan.py:54-62; one utterance, numpy in / numpy out"""
         c = torch.as_tensor(np.asarray(mel), dtype=torch.float32).unsqueeze(0).to(self.device)
-        return self.forward_batch(c).view(-1).cpu().numpy()
+        return self.forward_batch(c, check=True).view(-1).cpu().numpy()
+
+    def overflowed(self):
+        """True when a forward since the last call of this method (or construction) delivered non-finite pre-tanh samples, i.e. an fp16
+        operand overflowed.  Only meaningful once the caller has synchronised with the stream(s) of those forwards."""
+        n = self.ctx.vocoder_nonfinite()
+        bad = n != self._seen_bad
+        self._seen_bad = n
+        return bad
 
     # -- batched fast path (the reference calls spec2wav once per utterance, tasks/tts/dict_tts.py:255) ------
-    def forward_batch(self, mel, lens=None):
-        """mel [B,T,80] float32 cuda tensor, lens [B] int32 cuda tensor or None -> wav [B, T*hop] cuda tensor"""
+    def forward_batch(self, mel, lens=None, check=False):
+        """mel [B,T,80] float32 cuda tensor, lens [B] int32 cuda tensor or None -> wav [B, T*hop] cuda tensor.
+        check=True: synchronise the stream behind the forward and act on the overflow detector (AUTO: redo in DTTS_VOC_BF16X3 and keep
+        it; explicit fp16: raise).  check=False (pipelined callers): nothing synchronises here — call overflowed() after the waveform's
+        own synchronisation and redo the batch with check=True when it says so (dict_tts_amd/infer.py does)."""
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.dim() == 3
         mel = mel.contiguous()
         B, T, _ = mel.shape
@@ -140,32 +169,25 @@ class HifiGAN:
         if lens is not None:
             lens = lens.to(device=mel.device, dtype=torch.int32).contiguous()
         stream = torch.cuda.current_stream().cuda_stream
-        sampled = False
-        if self._auto_guard and self._guard_left == 0:   # past the initial guarded calls: every GUARD_EVERY-th call is guarded again
-            self._calls += 1
-            sampled = self._calls % self.GUARD_EVERY == 0
-            if sampled:
-                self.ctx.vocoder_range_guard(True)
-        self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
-        if self._guard_left or sampled:
-            n = self.ctx.vocoder_clamped(stream)   # (synchronises the stream: only during the guarded calls)
+        lens_p = lens.data_ptr() if lens is not None else None
+        self.ctx.hifigan_forward(mel.data_ptr(), lens_p, B, T, wav.data_ptr(), stream)
+        if self._census:
+            n = self.ctx.vocoder_clamped(stream)   # (synchronises the stream)
             if n:
-                if self._guard_raise or self._state_dict is None:
-                    raise abi.DttsError(f"DTTS_VOC_F16: {n} activations exceeded the fp16 range (the reference computes in fp32, "
-                                        f"modules/hifigan/hifigan.py:51-58); use precision='bf16x3'")
+                raise abi.DttsError(f"DTTS_VOC_F16: {n} activations exceeded the fp16 range (the reference computes in fp32, "
+                                    f"modules/hifigan/hifigan.py:51-58); use precision='bf16x3'")
+        if check and self.precision == abi.VOC_F16:
+            torch.cuda.current_stream().synchronize()
+            if self.overflowed():
+                if not (self._auto and self._state_dict is not None):
+                    raise abi.DttsError("DTTS_VOC_F16: an fp16 operand overflowed in this call (non-finite pre-tanh samples; the reference "
+                                        "computes in fp32, modules/hifigan/hifigan.py:51-58); use precision='bf16x3' or leave the precision to AUTO")
                 import warnings
-                warnings.warn(f"HifiGAN: {n} activations exceeded the fp16 range; switching to DTTS_VOC_BF16X3 and redoing this call")
-                self._guard_left = 0
-                self._auto_guard = False
+                warnings.warn("HifiGAN: an fp16 operand overflowed in this call; switching to DTTS_VOC_BF16X3 and redoing it")
                 self._build(self._state_dict, abi.VOC_BF16X3, False)
                 self._state_dict = None
-                self.ctx.hifigan_forward(mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T, wav.data_ptr(), stream)
-            elif sampled:
-                self.ctx.vocoder_range_guard(False)
-            elif self._guard_left > 0:
-                self._guard_left -= 1
-                if self._guard_left == 0:
-                    self.ctx.vocoder_range_guard(False)
+                self.fp16_status = "rejected"
+                self.ctx.hifigan_forward(mel.data_ptr(), lens_p, B, T, wav.data_ptr(), stream)
         return wav
 
     def to_int16(self, wav, lens=None, norm=False):
@@ -188,5 +210,5 @@ class HifiGAN:
         batch = torch.zeros(len(mels), T, self.config.get("audio_num_mel_bins", 80), dtype=torch.float32)
         for i, m in enumerate(mels):
             batch[i, :lens[i]] = torch.as_tensor(np.asarray(m), dtype=torch.float32)
-        wav = self.forward_batch(batch.to(self.device), torch.tensor(lens, dtype=torch.int32)).cpu().numpy()
+        wav = self.forward_batch(batch.to(self.device), torch.tensor(lens, dtype=torch.int32), check=True).cpu().numpy()
         return [wav[i, :lens[i] * self.hop] for i in range(len(mels))]

@@ -24,6 +24,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here (DTTS_API) are exported. */
+#if defined(__GNUC__)
+#define DTTS_API __attribute__((visibility("default")))
+#else
+#define DTTS_API
+#endif
+
 typedef struct dtts_ctx* dtts_handle;
 typedef void* dtts_stream; /* hipStream_t */
 
@@ -112,14 +119,14 @@ typedef struct dtts_config {
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */
-void dtts_default_config(dtts_config* cfg);
+DTTS_API void dtts_default_config(dtts_config* cfg);
 /* sizeof(dtts_config) as this library was compiled: a binding checks its own mirror of the struct against it. */
-int dtts_config_sizeof(void);
+DTTS_API int dtts_config_sizeof(void);
 
 /* Create / destroy a context on the current HIP device. */
-int dtts_create(const dtts_config* cfg, dtts_handle* out);
-void dtts_destroy(dtts_handle h);
-const char* dtts_last_error(dtts_handle h); /* h may be NULL: message of the last failed dtts_create */
+DTTS_API int dtts_create(const dtts_config* cfg, dtts_handle* out);
+DTTS_API void dtts_destroy(dtts_handle h);
+DTTS_API const char* dtts_last_error(dtts_handle h); /* h may be NULL: message of the last failed dtts_create */
 
 /*
  * Weight loading — replaces torch's load_state_dict for the two children the path uses:
@@ -130,13 +137,13 @@ const char* dtts_last_error(dtts_handle h); /* h may be NULL: message of the las
  * remove_weight_norm does at tasks/tts/ps_flow.py:262-268 and modules/hifigan/hifigan.py:144-151).
  * Unknown names (fvae.encoder.*, attn.*, enc_pos_proj.* ... — loaded but unused at inference) are accepted and ignored.
  */
-int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+DTTS_API int dtts_load_weight(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
 
 #define DTTS_PART_ACOUSTIC 1
 #define DTTS_PART_VOCODER 2
 #define DTTS_PART_FFT 4 /* an FFTBlocks state dict loaded under "fft.<key>"  */
 /* Fold, repack into MFMA fragment order and upload.  Fails with DTTS_E_NOENT naming the first missing tensor. */
-int dtts_finalize_weights(dtts_handle h, int parts);
+DTTS_API int dtts_finalize_weights(dtts_handle h, int parts);
 
 /*
  * Acoustic model, phase 1 — replaces run_text_encoder (modules/dict_tts/model.py:84-110): S2PA dictionary
@@ -148,7 +155,7 @@ int dtts_finalize_weights(dtts_handle h, int parts);
  * On return *T_mel_host is the frame count padded to frames_multiple (model.py:98-100).  This call
  * synchronises the stream once to read that scalar when mel2word is NULL.
  */
-int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+DTTS_API int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
                          const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
                          const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k,
                          int P, int32_t* T_mel_host, dtts_stream stream);
@@ -165,7 +172,7 @@ int dtts_text2mel_encode(dtts_handle h, const int64_t* word_tokens_dev, const fl
  * logits = K . q and context = Wo sum_l w_l V_l in the reference's own association order.  Consequences: the acoustic weights
  * must be finalized BEFORE this call (DTTS_E_STATE otherwise), and re-loading them requires a new upload.
  */
-int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off_host, const float* keys_host,
+DTTS_API int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off_host, const float* keys_host,
                            const float* values_host, const float* key_map_host, const int32_t* pin_off_host,
                            const int64_t* pinyin_host, const int64_t* pinyin_map_host);
 /*
@@ -174,7 +181,7 @@ int dtts_dict_table_upload(dtts_handle h, int n_entries, const int32_t* tok_off_
  * padding.  L_k / P are the batch maxima the collated tensors would have had (they size dict_attn / pron_attn).
  * Results are identical to dtts_text2mel_encode on the tensors collated from the same table.
  */
-int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
+DTTS_API int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
                              const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k,
                              int P, int32_t* T_mel_host, dtts_stream stream);
 
@@ -184,7 +191,7 @@ int dtts_text2mel_encode_ids(dtts_handle h, const int64_t* word_tokens_dev, cons
  * CPU RNG; here it is an explicit input for parity runs) or NULL: N(0,1) drawn on the device (counter-based, a new stream
  * per call).  mel_out [B,T_mel,80] f32.
  */
-int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev, dtts_stream stream);
+DTTS_API int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev, dtts_stream stream);
 
 /*
  * Single-call forms and names of SURVEY.md 8(b).  dtts_text2mel_forward = dtts_text2mel_encode + dtts_text2mel_decode +
@@ -195,17 +202,17 @@ int dtts_text2mel_decode(dtts_handle h, const float* z_p_dev, float* mel_out_dev
  * for bit, so parity runs pass z_p); pron_attn [B,T_w,P] / dur [B,T_w] may be NULL.  dtts_text2mel_plan is the
  * two-phase entry (= dtts_text2mel_encode: returns T_mel after the duration kernel); dtts_load_weights = dtts_load_weight.
  */
-int dtts_load_weights(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
-int dtts_text2mel_plan(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+DTTS_API int dtts_load_weights(dtts_handle h, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+DTTS_API int dtts_text2mel_plan(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
                        const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
                        const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, int B, int T_w, int L_k, int P,
                        int32_t* T_mel_host, dtts_stream stream);
-int dtts_text2mel_forward(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
+DTTS_API int dtts_text2mel_forward(dtts_handle h, const int64_t* word_tokens_dev, const float* keys_dev, const float* values_dev,
                           const float* key_map_dev, const int64_t* pinyin_dev, const int64_t* pinyin_map_dev,
                           const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, const float* z_p_dev, int z_cap,
                           int B, int T_w, int L_k, int P, float* mel_out_dev, int mel_cap, int64_t* T_mel_out_host,
                           float* pron_attn_dev, float* dur_dev, dtts_stream stream);
-int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
+DTTS_API int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens_dev, const int32_t* entry_ids_dev,
                               const int64_t* pron_modified_dev, const int64_t* mel2word_dev, int T_m2w, const float* z_p_dev,
                               int z_cap, int B, int T_w, int L_k, int P, float* mel_out_dev, int mel_cap, int64_t* T_mel_out_host,
                               float* pron_attn_dev, float* dur_dev, dtts_stream stream);
@@ -220,7 +227,7 @@ int dtts_text2mel_forward_ids(dtts_handle h, const int64_t* word_tokens_dev, con
 #define DTTS_OUT_CONTEXT 7          /* [B,T_w,hidden] f32 S2PA context              */
 #define DTTS_OUT_MEL_LENS 8         /* [B] i32 frames with mel2word > 0 AFTER the padding to frames_multiple (the frames the
                                       reference's B = 1 inference vocodes: an utterance that reaches T_mel keeps its pad frames) */
-int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stream);
+DTTS_API int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stream);
 
 /*
  * Length regulator alone — replaces the integer part of add_dur + LengthRegulator.forward
@@ -229,7 +236,7 @@ int dtts_text2mel_fetch(dtts_handle h, int what, void* dst_dev, dtts_stream stre
  * gets ones.  Writes mel2word [B,cap] i64 (1-based word index, 0 = padding; columns beyond the longest utterance
  * are zero) and, on the host, the per-batch maximum frame count (unpadded).  Returns DTTS_E_INVAL if it exceeds cap.
  */
-int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ilens_dev, int B, int T_w, int64_t* mel2word_dev,
+DTTS_API int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ilens_dev, int B, int T_w, int64_t* mel2word_dev,
                          int cap, int32_t* T_max_host, dtts_stream stream);
 
 /*
@@ -239,9 +246,9 @@ int dtts_length_regulate(dtts_handle h, const float* dur_dev, const int32_t* ile
  * produces for mel[b,:lens[b]] alone, samples past lens[b]*hop are zero.  B <= DTTS_MAX_VOCODER_BATCH per call in the fused modes.
  */
 #define DTTS_MAX_VOCODER_BATCH 2048
-int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* lens_dev, int B, int T, float* wav_dev,
+DTTS_API int dtts_hifigan_forward(dtts_handle h, const float* mel_dev, const int32_t* lens_dev, int B, int T, float* wav_dev,
                          dtts_stream stream);
-int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
+DTTS_API int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
 
 /*
  * FastSpeech FFT block stack — replaces FFTBlocks.forward (modules/fastspeech/tts_modules.py:495-523) at inference:
@@ -252,7 +259,7 @@ int dtts_hifigan_hop(dtts_handle h); /* product of upsample_rates (256) */
  * make_positions(x[...,0]) (utils/tts_utils.py:6-18): a frame whose first channel is exactly 0 gets row 0.
  * Weights: dtts_load_weight("fft.<key of FFTBlocks.state_dict()>"), dtts_finalize_weights(h, DTTS_PART_FFT).
  */
-int dtts_fft_blocks_forward(dtts_handle h, const float* x_dev, const int32_t* lens_dev, const float* pos_table_dev, int n_pos,
+DTTS_API int dtts_fft_blocks_forward(dtts_handle h, const float* x_dev, const int32_t* lens_dev, const float* pos_table_dev, int n_pos,
                             int B, int T, float* y_dev, dtts_stream stream);
 
 /*
@@ -262,30 +269,48 @@ int dtts_fft_blocks_forward(dtts_handle h, const float* x_dev, const int32_t* le
  * per utterance over its own lens[b]*hop samples: norm != 0 -> w / max|w| ; w * 32767 (fp32) ; truncating cast.
  * out [B, T*hop] i16, samples past an utterance's end are 0.
  */
-int dtts_wav_to_int16(dtts_handle h, const float* wav_dev, const int32_t* lens_dev, int B, int T, int norm, int16_t* out_dev,
+DTTS_API int dtts_wav_to_int16(dtts_handle h, const float* wav_dev, const int32_t* lens_dev, int B, int T, int norm, int16_t* out_dev,
                       dtts_stream stream);
 
 /* Seed of the device-side prior sample (z_p == NULL in dtts_text2mel_decode / _forward*).  Every context starts from a seed mixed from
  * the time, the process id, the device and a per-process instance count, so that data-parallel ranks and restarts draw different
  * noise (the reference draws from torch's global RNG, modules/dict_tts/fvae_semantics.py:110-111); setting it makes a run repeatable. */
-int dtts_set_noise_seed(dtts_handle h, uint64_t seed);
+DTTS_API int dtts_set_noise_seed(dtts_handle h, uint64_t seed);
 
-/* fp16 range guard (DTTS_VOC_F16).  The ResBlock convolutions round their activations to fp16: leaky_relu(v) > 65504 saturates and
- * v * 0.1 < -65504 overflows, where the reference computes in fp32 (modules/hifigan/hifigan.py:51-58).  While the guard is on, the
- * fused ResBlock kernels run an instantiation that COUNTS such activations (a few % slower); dtts_vocoder_clamped returns the count
- * accumulated since the last reset (it synchronises `stream`).  A non-zero count means this mode is not valid for the checkpoint /
- * input at hand: use DTTS_VOC_BF16X3 (dict_tts_amd/vocoder.py does that automatically when the precision was not chosen explicitly). */
-int dtts_vocoder_range_guard(dtts_handle h, int enable);
-int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream stream);
+/* fp16 range guard (DTTS_VOC_F16), the CENSUS form.  The ResBlock convolutions convert their activations to fp16: |v| > 65504 becomes
+ * +-inf, where the reference computes in fp32 (modules/hifigan/hifigan.py:51-58).  While the guard is on, the fused ResBlock kernels run an
+ * instantiation that COUNTS such activations at every one of the 72 conversion points (a few % slower); dtts_vocoder_clamped returns the
+ * count accumulated since the last reset (it synchronises `stream`).  A testing / diagnosis aid: the always-on detector below needs no mode. */
+DTTS_API int dtts_vocoder_range_guard(dtts_handle h, int enable);
+DTTS_API int dtts_vocoder_clamped(dtts_handle h, int64_t* count, int reset, dtts_stream stream);
+
+/* fp16 validity of DTTS_VOC_F16 as a DECISION, in two parts (the reference computes the ResBlocks in fp32, modules/hifigan/hifigan.py:51-58):
+ *
+ * (1) ALWAYS-ON detector.  The fp16 conversion of the ResBlock operands does not saturate: an activation beyond +-65504 becomes +-inf,
+ *     every sum it enters is inf / NaN from there on, and it reaches conv_post as a non-finite pre-tanh value.  The conv_post epilogue of
+ *     EVERY forward (release instantiations included, no mode to switch on) writes NaN for such a sample instead of tanh's plausible +-1
+ *     and counts it; dtts_hifigan_forward copies the running count to pinned host memory behind its last kernel.  dtts_vocoder_nonfinite
+ *     returns that word WITHOUT synchronising: once the caller has synchronised with the forward's stream (it must, to read the waveform)
+ *     the value covers that forward.  The count is cumulative over the context's life; compare it with the value before the call.  A call
+ *     that overflowed is therefore ALWAYS reported (dict_tts_amd/vocoder.py redoes it in DTTS_VOC_BF16X3, or raises when fp16 was demanded).
+ * (2) STATIC bound, computed by dtts_finalize_weights from the folded weights.  worst_case: an upper bound of every value the ResBlocks round
+ *     to fp16, for ANY mel with |mel| <= mel_abs_max (per-channel L1 propagation: |b| + sum|w| * bound_in through all 72 convolutions; the
+ *     reference's log10-mel lies in [-6, 1.5], egs/egs_bases/tts/base.yaml:59-60).  worst_case < 65504 PROVES that no call in that range can
+ *     overflow.  rms_estimate: the propagated root-mean-square of the largest such channel (independence assumed: an estimate, not a bound);
+ *     a checkpoint whose estimate already nears 65504 / 16 should not be run in fp16 at all.  For trained generators the worst case is
+ *     astronomically loose (it compounds sum|w| ~ 10-40 per convolution), so part (1) is what protects them.  Either pointer may be NULL.
+ *     Other precisions: both 0 (bf16 has fp32's exponent range). */
+DTTS_API int dtts_vocoder_nonfinite(dtts_handle h, int64_t* count);
+DTTS_API int dtts_vocoder_fp16_bound(dtts_handle h, float mel_abs_max, double* worst_case, double* rms_estimate);
 
 /* Memory-safety mode (dtts_config.debug_redzone = 1; a testing aid with no counterpart in the reference — the kernels behind this ABI
  * address raw HBM).  Every workspace buffer of the last encode / decode / vocoder / FFT-block call and every weight pack / table sits
  * between two 4 KiB red zones filled with 0xFF, and the workspaces are filled with 0xFF (NaN) before each forward.  dtts_debug_check
  * synchronises `stream` and counts the red-zone bytes that are no longer 0xFF (= an out-of-range WRITE; dtts_last_error names the first
  * damaged zone); an out-of-range or stale READ that is consumed shows up as NaN in the outputs.  DTTS_E_STATE without the mode. */
-int dtts_debug_check(dtts_handle h, int64_t* damaged_bytes, dtts_stream stream);
+DTTS_API int dtts_debug_check(dtts_handle h, int64_t* damaged_bytes, dtts_stream stream);
 /* self-test of the mode: damages one red-zone byte (as an off-by-one store would); the next dtts_debug_check must report it */
-int dtts_debug_poke(dtts_handle h, dtts_stream stream);
+DTTS_API int dtts_debug_poke(dtts_handle h, dtts_stream stream);
 
 /*
  * Instrumentation used by bench.py: accumulated device time (hipEvent pairs recorded on the caller's stream
@@ -299,9 +324,9 @@ int dtts_debug_poke(dtts_handle h, dtts_stream stream);
 #define DTTS_TIMER_STAGE_FVAE 5         /* 'fvae'         modules/dict_tts/model.py:57  = dtts_text2mel_decode (gather-expand + prior flow + decoder)       */
 #define DTTS_TIMER_STAGE_HIFIGAN 6      /* 'hifigan'      vocoders/hifigan.py:59        = dtts_hifigan_forward                                              */
 #define DTTS_TIMER_COUNT 7
-int dtts_timer_enable(dtts_handle h, int which);
-int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches); /* synchronises */
-int dtts_timer_reset(dtts_handle h);
+DTTS_API int dtts_timer_enable(dtts_handle h, int which);
+DTTS_API int dtts_timer_read(dtts_handle h, int which, double* ms_total, int64_t* launches); /* synchronises */
+DTTS_API int dtts_timer_reset(dtts_handle h);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,31 @@ def test_header_symbols_exported(lib):
     assert declared == set(abi.EXPORTS)
 
 
+def test_library_exports_exactly_the_header(lib):
+    """the release library is sealed (-fvisibility=hidden + a linker version script): `nm -D` shows the dtts_* entry points
+    of include/dicttts_hip.h and NOTHING else — no kernel host stubs, no C++ template instantiations, no internal helpers."""
+    import subprocess
+    text = open(os.path.join(ROOT, "include", "dicttts_hip.h")).read()
+    declared = set(re.findall(r"\b(dtts_[a-z0-9_]+)\s*\(", text))
+    out = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+    assert len(re.findall(r"^DTTS_API ", text, flags=re.M)) == len(declared)
+
+
+def test_release_library_refuses_untested_tune_bits(lib):
+    """a tune_flags bit without a parity / bit-identity test exists only in -DDTTS_ABLATE builds; the release library refuses
+    it loudly (argument validation: no device needed) instead of ignoring it.  The tested bits (8, 9, 12, 13, 14) pass this check."""
+    cfg = abi.default_config()
+    for bit in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 16, 17):
+        cfg.tune_flags = 1 << bit
+        h = abi.C.c_void_p()
+        assert lib.dtts_create(abi.C.byref(cfg), abi.C.byref(h)) == -22, bit
+        assert b"tune_flags" in lib.dtts_last_error(None)
+    text = open(os.path.join(ROOT, "dict_tts_amd", "csrc", "tune_env.h")).read()
+    assert "TUNE_RELEASE_MASK = (1 << 8) | (1 << 9) | (1 << 12) | (1 << 13) | (1 << 14)" in text
+
+
 def test_default_config_matches_reference_hparams(lib):
     cfg = abi.default_config()
     assert (cfg.hidden_size, cfg.num_heads, cfg.enc_ffn_kernel_size, cfg.gloss_dim) == (192, 2, 5, 768)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[0]: one Biaobei sentence, B=1, text -> mel -> wav, one stream; wall time per utterance and (under rocprofv3) the
-kernel-time share of it.  usage: python tools/b1_bench.py [reps]"""
+kernel-time share of it.  usage: python tools/b1_bench.py [reps] [--lib build/x/variant.so]"""
 import os
 import sys
 import time
@@ -12,6 +12,10 @@ import torch
 from dict_tts_amd import abi, model, synth, vocoder
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+if "--lib" in sys.argv:   # A/B runs: another build of the library, selected by path (nothing is copied over the release library)
+    i = sys.argv.index("--lib")
+    abi.load_library(os.path.abspath(sys.argv[i + 1]))
+    del sys.argv[i:i + 2]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 sd = synth.dict_tts_state_dict(1234)
 sd["dur_predictor.linear.0.bias"] = np.array([3.09], np.float32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Text->mel micro-benchmark used while tuning the acoustic model (not the headline bench): the first Biaobei batch of B
 utterances through dtts_text2mel_encode_ids + dtts_text2mel_decode on one stream, nothing else on the GPU.
-usage: python tools/t2m_bench.py [--B 60] [--iters 20]"""
+usage: python tools/t2m_bench.py [--B 60] [--iters 20] [--lib build/x/variant.so]"""
 import argparse
 import os
 import sys
@@ -15,7 +15,10 @@ from dict_tts_amd import abi, model, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=60)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--lib", default=None, help="path of the library build to load instead of the in-tree release library (A/B runs)")
 a = ap.parse_args()
+if a.lib:
+    abi.load_library(os.path.abspath(a.lib))
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 sd = synth.dict_tts_state_dict(1234)
 sd["dur_predictor.linear.0.bias"] = np.array([3.09], np.float32)

@@ -18,7 +18,10 @@ ap.add_argument("--T", type=int, default=740)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--precision", default="f16")
 ap.add_argument("--tune", type=int, default=0, help="dtts_config.tune_flags (A/B switches, include/dicttts_hip.h)")
+ap.add_argument("--lib", default=None, help="path of the library build to load instead of the in-tree release library (A/B runs: nothing is copied over it)")
 a = ap.parse_args()
+if a.lib:
+    abi.load_library(os.path.abspath(a.lib))
 T_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config={**synth.hifigan_config(), "dtts_tune_flags": a.tune},
                       precision=abi.VOC_PRECISIONS[a.precision])
@@ -39,6 +42,8 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 ms, n = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
 frames = int(lens.sum())
+import hashlib
+print(f"wav md5 {hashlib.md5(wav.cpu().numpy().tobytes()).hexdigest()[:12]}  sum|wav| {float(wav.abs().double().sum()):.6f}")   # bit-identity across builds
 print(f"frames {frames}  wall {dt * 1e3:.2f} ms/forward  conv-kernel {ms / a.iters:.2f} ms/forward  "
       f"{614105088 * frames / (ms / a.iters * 1e-3) / 1e12:.1f} TFLOP/s  ({frames / dt:.0f} frames/s vocoder-only)")
 if os.environ.get("DTTS_CALIB"):
