@@ -229,6 +229,7 @@ def main():
                          "full: no budget, B=60 batched variant")
     ap.add_argument("--cpu-budget", type=float, default=420.0, help="seconds the 'protocol' CPU leg may spend on its repetitions")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures / per-stage / second-mode measurements")
+    ap.add_argument("--voc-priority", type=int, default=0, help="HIP stream priority of the vocoder stream (two-stream pipeline): 0 normal, -1 high")
     ap.add_argument("--voc-tune", type=int, default=0, help="dtts_config.tune_flags of the vocoder context (A/B switches, include/dicttts_hip.h)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the vocoder on the text->mel stream (default: vocoder of batch i on a second HIP stream, "
@@ -341,7 +342,7 @@ def main():
     gather_info = {"enabled": gather_on, "backend": ("gloo (one-device test hook)" if one_dev else "rccl") if world > 1 else None,
                    "calls": 0, "disabled_reason": None if gather_on or world == 1 else "--no-gather"}
     pipelined = not args.no_pipeline
-    voc_stream = torch.cuda.Stream(device=dev) if pipelined else None
+    voc_stream = torch.cuda.Stream(device=dev, priority=args.voc_priority) if pipelined else None
     comm_stream = torch.cuda.Stream(device=dev) if gather_on else None
     ptr = lambda t: None if t is None else t.data_ptr()
     state = {"last": None, "k": 0}
@@ -541,7 +542,7 @@ def main():
             stages["s2pa_roofline"] = {"bound": f"hbm (nominal) - the kernel is LATENCY-bound: {s2pa_ms / max(s2pa_n, 1) * 1e3:.1f} us per launch, ~15 live rows per word, "
                                                 "one dependent chain entry -> offsets -> key_map -> rows -> reductions per workgroup (DESIGN.md 3.3)",
                                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                       "kernel": "dtts::s2pa_kernel<1, 8> (resident table of PRE-PROJECTED rows, gathered by entry id)",
+                                       "kernel": "dtts::s2pa_kernel<1, 3, true> (resident table of PRE-PROJECTED rows, gathered by entry id; 16 lanes per row)",
                                        "avg_launch_ms": s2pa_ms / max(s2pa_n, 1), "avg_launch_us": s2pa_ms / max(s2pa_n, 1) * 1e3,
                                        "algorithmic_bytes": f"{row_bytes} B x live gloss rows of the batch's entries (fp32 K + V, 192 wide each; "
                                                             "the tensor API reads 6144 B per row: raw 768-wide key + value)",
@@ -595,6 +596,41 @@ def main():
                                    "within_1e-3_of_half": int(((fracd < 1e-3) & wmask).sum().item()),
                                    "note": "a word whose exp(dur)-1 sits this close to x.5 may round either way between two fp32 summation "
                                            "orders (GPU vs CPU thread counts); tests/test_gpu_parity.py::test_config2 prints n_ties / n_flips"}
+        # ---- the two single-utterance shapes of BASELINE.json: configs[0] (one Biaobei sentence, B = 1) and configs[3] (long
+        # form: 1,000 characters, teacher-forced 5 frames per character -> ~5 k mel frames, B = 1), serial text->mel -> vocoder on one stream
+        # with the resident table; 5 repetitions after 2 warm-ups.  Small grids: a launch lasts as long as its slowest workgroup's tile chain.
+        def single_utterance(sent, frames_per_char=None):
+            ib1 = synth.make_id_batch([sent], table)
+            d1 = {k: T(ib1[k]).to(dev) for k in ("word_tokens", "entry_ids", "pron_modified")}
+            m2w = None
+            if frames_per_char:
+                m2w_t = T(synth.teacher_mel2word(ib1["word_tokens"], frames_per_char, frames_per_char)).to(dev)
+                m2w = (m2w_t.data_ptr(), int(m2w_t.shape[1]))
+            t2m = vo = 0.0
+            reps = 5
+            for it in range(reps + 2):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                T_m = m.ctx.text2mel_encode_ids(ptr(d1["word_tokens"]), ptr(d1["entry_ids"]), ptr(d1["pron_modified"]), m2w, 1,
+                                                int(ib1["word_tokens"].shape[1]), ib1["L_k"], ib1["P"], stream)
+                mel1 = torch.empty(1, T_m, 80, device=dev)
+                m.ctx.text2mel_decode(None, mel1.data_ptr(), stream)
+                lens1 = torch.empty(1, dtype=torch.int32, device=dev)
+                m.ctx.fetch(abi.OUT_MEL_LENS, lens1.data_ptr(), stream)
+                ev[1].record()
+                voc.forward_batch(mel1, lens1)
+                ev[2].record()
+                torch.cuda.synchronize()
+                if it >= 2:
+                    t2m += ev[0].elapsed_time(ev[1]) / reps
+                    vo += ev[1].elapsed_time(ev[2]) / reps
+            fr1 = int(lens1.sum().item())
+            return {"characters": len(sent), "mel_frames": fr1, "audio_s": fr1 * hop / 22050.0, "text2mel_ms": t2m, "vocoder_ms": vo, "ms": t2m + vo,
+                    "mel_frames_per_s": fr1 / ((t2m + vo) * 1e-3), "rtf": (t2m + vo) * 1e-3 / (fr1 * hop / 22050.0)}
+        stages["b1"] = {**single_utterance(st["sentences"][0]), "what": "BASELINE configs[0] on the GPU: one Biaobei sentence, B = 1, predicted durations"}
+        stages["long_form"] = {**single_utterance([w for sn in st["sentences"] for w in sn][:1000], 5),
+                               "what": "BASELINE configs[3]: 1,000 characters (T_w = 1,002), teacher-forced 5 frames per character, B = 1"}
+        m.ctx.text2mel_encode_ids(ptr(d["word_tokens"]), ptr(d["entry_ids"]), ptr(d["pron_modified"]), None, hb["B"], hb["T_w"], hb["L_k"], hb["P"], stream)   # (back on the benched batch)
         # the same vocoder kernels on the last batch with nothing else on the GPU (in the timed region they share the CUs
         # with the next batch's text->mel kernels), and the all-bf16 mode beside the default one
         mel_l, lens_l = state["last"][0], state["last"][1]

@@ -2379,7 +2379,11 @@ int dtts_text2mel_fetch(dtts_handle h, int what, void* dst, dtts_stream stream) 
         case DTTS_OUT_PRON_ATTN: src = h->pron_attn; bytes = rows * h->P * 4; break;
         case DTTS_OUT_DUR: src = h->dur; bytes = rows * 4; break;
         case DTTS_OUT_MEL2WORD: src = h->m2w; bytes = mrows * 8; break;
-        case DTTS_OUT_DICT_ATTN: src = h->dict_attn; bytes = (size_t)h->B * h->L_k * h->T_w * 4; break;
+        case DTTS_OUT_DICT_ATTN:
+            // kept as [B][T_w][L_k] (every word's weights one contiguous row, written coalesced by s2pa_kernel); the reference returns the
+            // transposed view weights.permute(0, 1, 3, 2) = [B, 1, L_k, T_w] (dict_encoder.py:66): produced here, when somebody asks for it
+            LAUNCH(transpose_cf_to_cl_launch(h->dict_attn, (float*)dst, h->B, h->T_w, h->L_k, s));
+            return DTTS_OK;
         case DTTS_OUT_WORD_ENCODER_OUT: src = h->weo; bytes = rows * h->cfg.hidden_size * 4; break;
         case DTTS_OUT_X_MASK: src = h->x_mask; bytes = mrows * 4; break;
         case DTTS_OUT_CONTEXT: src = h->context; bytes = rows * h->cfg.hidden_size * 4; break;

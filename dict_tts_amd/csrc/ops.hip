@@ -512,23 +512,57 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
 // S2PA dictionary attention: one block per word, gloss rows streamed once with 16 B/lane loads.
 constexpr int S2PA_LMAX = 1024, S2PA_DMAX4 = 3;  // D <= 768 (3 float4 per lane), L_k <= 1024
 #ifndef S2PA_RU_P
-#define S2PA_RU_P 8
+#define S2PA_RU_P 4
 #endif
 constexpr int S2PA_NW = 4, S2PA_RU = 4;           // waves per workgroup; gloss rows a wave keeps in flight (3 x 16 B per lane each)
 constexpr int S2PA_NTHR = S2PA_NW * 64;
 
+// The workgroup's LDS, carved from DYNAMIC shared memory sized for the launch's L_k and row width D (round 5): the static form was sized for
+// L_k = 1024 and D = 768 (22.5 KB), which capped the kernel at 6 workgroups per CU — the 1,620 words of a B = 60 batch took a second,
+// almost empty round of workgroups.  At L_k ~ 150, D = 192 a workgroup needs 5.6 KB and all words are resident at once (8 per CU).
 struct S2paShared {
-    float lg[S2PA_LMAX];
-    float km[S2PA_LMAX];
-    unsigned short idx[S2PA_LMAX];
-    __attribute__((aligned(16))) float part[S2PA_NW][768];
-    float red[2 * S2PA_NW];
-    float wmax[S2PA_NW];
-    float sense[16];
-    float pw[64];
-    int pid[64 + 4];
-    int n_live;
+    float* lg;             // [Lp] logits -> weights
+    float* km;             // [Lp] key_map row
+    float* part;           // [NW][D] the waves' partial context sums (16-byte aligned rows)
+    float* red;            // [16 NW]
+    float* wmax;           // [NW]
+    float* sense;          // [16]
+    float* pw;             // [64]
+    int* pid;              // [64 + 4]
+    int* n_live;           // [1]
+    unsigned short* idx;   // [Lp] list of the live rows
+    int D;
 };
+__host__ __device__ inline size_t s2pa_lds_bytes(int L, int D) {
+    const size_t Lp = (size_t)((L + 63) & ~63);
+    return Lp * 4 * 2 + (size_t)S2PA_NW * D * 4 + (16 * S2PA_NW + S2PA_NW + 16 + 64 + 68 + 4) * 4 + Lp * 2;
+}
+__device__ __forceinline__ S2paShared s2pa_carve(char* base, int L, int D) {
+    const int Lp = (L + 63) & ~63;
+    S2paShared sh;
+    float* f = (float*)base;
+    sh.part = f;                 // first: the dynamic-LDS base is 16-byte aligned, every row is D * 4 bytes (D % 4 == 0)
+    f += S2PA_NW * D;
+    sh.lg = f;
+    f += Lp;
+    sh.km = f;
+    f += Lp;
+    sh.red = f;                  // [16 NW]: the block reductions use 2 NW of it, the sense merge all of it
+    f += 16 * S2PA_NW;
+    sh.wmax = f;
+    f += S2PA_NW;
+    sh.sense = f;
+    f += 16;
+    sh.pw = f;
+    f += 64;
+    sh.pid = (int*)f;
+    f += 68;
+    sh.n_live = (int*)f;
+    f += 4;
+    sh.idx = (unsigned short*)f;
+    sh.D = D;
+    return sh;
+}
 // where one word's rows come from: the collated tensors, or the resident table
 struct S2paRow {
     const float* kmr = nullptr;
@@ -544,15 +578,17 @@ __device__ __forceinline__ S2paRow s2pa_row(const S2paArgs& a, int row) {
     r.Prow = a.P;
     r.special = 0;
     if (a.entry) {
-        const int e = a.entry[row];
+        // (readfirstlane: the row is the workgroup's, but hipcc fetches these with vector loads; as VGPR values they would put every
+        // pointer derived below into VGPR pairs)
+        const int e = __builtin_amdgcn_readfirstlane(a.entry[row]);
         if (e >= 0) {
-            const int o = a.t_off[e];
-            r.Lrow = min(a.t_off[e + 1] - o, a.L_k);
+            const int o = __builtin_amdgcn_readfirstlane(a.t_off[e]);
+            r.Lrow = min(__builtin_amdgcn_readfirstlane(a.t_off[e + 1]) - o, a.L_k);
             r.kmr = a.t_key_map + o;
             r.kb = (const f32x4*)(a.t_keys + (long long)o * a.D);
             r.vb = (const f32x4*)(a.t_values + (long long)o * a.D);
-            const int po = a.t_poff[e];
-            r.Prow = min(a.t_poff[e + 1] - po, a.P);
+            const int po = __builtin_amdgcn_readfirstlane(a.t_poff[e]);
+            r.Prow = min(__builtin_amdgcn_readfirstlane(a.t_poff[e + 1]) - po, a.P);
             r.pin = a.t_pinyin + po;
             r.pmr = a.t_pinyin_map + po;
         } else {
@@ -591,10 +627,10 @@ __device__ __forceinline__ int s2pa_list(S2paShared& sh, const S2paRow& r, int L
         }
         if (cnt == 0)
             for (int l = lane; l < r.Lrow; l += 64) sh.idx[l] = (unsigned short)l;
-        if (lane == 0) sh.n_live = cnt;
+        if (lane == 0) *sh.n_live = cnt;
     }
     __syncthreads();
-    return sh.n_live;
+    return *sh.n_live;
 }
 __device__ __forceinline__ float s2pa_block_max(S2paShared& sh, float v, int tid) {
     v = wave_max(v);
@@ -635,21 +671,25 @@ __device__ __forceinline__ S2paPre s2pa_prefetch(const S2paArgs& a, const S2paRo
 // returns it), the sense merge, the forced-pronunciation rule and the pinyin-embedding mix
 __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, const S2paPre& pre, int row, int b, int t, int tid) {
     const int L = a.L_k;
-    float* da = a.dict_attn + ((long long)b * L) * a.T_w + t;
-    for (int l = tid; l < L; l += S2PA_NTHR) da[(long long)l * a.T_w] = sh.lg[l];
-    // sense weights s_i = sum_l w[l] [key_map == i]: wave 0, lane = 16 j + i sums the rows l = j (mod 4) of sense i (4
-    // independent LDS streams instead of one 148-long dependent chain), partials merged in a fixed order
-    if (tid < 64) {
+    // the word's weights as ONE contiguous row of the internal [B][T_w][L_k] tensor (round 5; the reference's transposed [B,1,L_k,T_w] view
+    // is produced by dtts_text2mel_fetch: a word's column there is L_k scattered 4-byte stores, 243 k of them per B = 60 batch)
+    float* da = a.dict_attn + (long long)row * L;
+    for (int l = tid; l < L; l += S2PA_NTHR) da[l] = sh.lg[l];
+    // sense weights s_i = sum_l w[l] [key_map == i]: thread 16 j + i sums the rows l = j (mod 16) of sense i (16 independent LDS streams of
+    // L / 16 steps instead of one L-long dependent chain), the partials of a wave are joined by two shuffles, the four waves' in a fixed order
+    {
         const int i = tid & 15, j = tid >> 4;
         float s = 0.f;
         if (i >= 1) {
 #pragma unroll 4
-            for (int l = j; l < L; l += 4) s += (sh.km[l] == (float)i) ? sh.lg[l] : 0.f;
+            for (int l = j; l < L; l += 16) s += (sh.km[l] == (float)i) ? sh.lg[l] : 0.f;
         }
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (tid < 16) sh.sense[tid] = s;
+        if ((tid & 63) < 16) sh.red[(tid >> 6) * 16 + i] = s;   // (red: 4 x 16 floats here; its reduction uses are over)
     }
+    __syncthreads();
+    if (tid < 16) sh.sense[tid] = ((sh.red[tid] + sh.red[16 + tid]) + sh.red[32 + tid]) + sh.red[48 + tid];
     __syncthreads();
     if (tid < a.P && tid < 64) {
         const long long pm = pre.pm;
@@ -690,25 +730,84 @@ __device__ __forceinline__ void s2pa_tail(S2paShared& sh, const S2paArgs& a, con
 // part - 235 us.  Net zero by the stream's clock, so the simple form stays.)
 // DM4: float4 pieces of a row per lane (3: the 768-wide gloss embeddings; 1: rows <= 256 wide = the PRE-PROJECTED table, K = key Wk^T /
 // V = value Wv^T, 192 wide); RU: 2 x the rows of a chunk (a wave keeps RU / 2 key rows + RU / 2 value rows, or RU aliased rows, in flight).
-template <int DM4, int RU>
-__global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
-    __shared__ S2paShared sh;
+#ifndef S2PA_WPE
+#define S2PA_WPE 6   // waves per SIMD = workgroups per CU of the table form: 80 VGPRs without a spill (7: 2 spilled, same time; 8: 18 spilled, 2x slower)
+#endif
+#ifdef S2PA_STAMP   // phase stamps of every workgroup (tools/s2pa_stamps.py; a variant build, never the release library)
+__device__ unsigned long long s2pa_stamps[8 * 4096];
+extern "C" __attribute__((visibility("default"))) int dtts_debug_s2pa_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(s2pa_stamps), sizeof(s2pa_stamps));
+}
+#define S2_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) s2pa_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S2_STAMP(i)
+#endif
+// (the projected-table form, DM4 = 1: 8 waves per SIMD = 8 workgroups per CU, so that every word of a B = 60 batch is resident at once)
+// SPEC: the resident-table form (a.entry != null): the entry's contiguous rows streamed speculatively (below); its own instantiation, so that
+// the list-driven loops of the tensor API do not count against its registers
+template <int DM4, int RU, bool SPEC>
+#ifndef S2PA_WPE3
+#define S2PA_WPE3 4
+#endif
+__global__ __launch_bounds__(S2PA_NTHR, DM4 == 1 ? S2PA_WPE : S2PA_WPE3) void s2pa_kernel(const S2paArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char s2pa_smem[];
+    S2paShared sh = s2pa_carve(s2pa_smem, a.L_k, a.D);
+    S2_STAMP(0);
     constexpr int S2PA_DMAX4 = DM4;   // (shadows the namespace constant: every per-lane row array below has DM4 pieces)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x;  // b * T_w + t
-    const int b = row / a.T_w, t = row % a.T_w;
+    // workgroup i -> word (b, t) = (i % B, i / B): position-major.  The kernel lasts as long as its longest words (tools/s2pa_stamps.py), and in
+    // the collated tensors those are the BOS rows (t = 0: key_map all ones, L_k "live" zero vectors — 130 rows against ~36 for a dictionary
+    // word): they are dispatched FIRST and stream beside everything else instead of starting in the second round of workgroups.
+    const int b = blockIdx.x % a.B, t = blockIdx.x / a.B;
+    const int row = b * a.T_w + t;
     const int L = a.L_k, D4 = a.D / 4;
     const S2paRow r = s2pa_row(a, row);
     const S2paPre pre = s2pa_prefetch(a, r, row, tid);
     // the query, 12 floats per lane
     f32x4 q[S2PA_DMAX4];
     const f32x4* qp = (const f32x4*)(a.qk + (long long)row * a.D);
+    if constexpr (!SPEC) {
 #pragma unroll
-    for (int cc = 0; cc < S2PA_DMAX4; ++cc) q[cc] = (lane + 64 * cc < D4) ? qp[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int n = s2pa_list(sh, r, L, tid);
+        for (int cc = 0; cc < S2PA_DMAX4; ++cc) q[cc] = (lane + 64 * cc < D4) ? qp[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // a word past the end of its utterance: its weights are still returned (dict_attn), its context is zeroed by the
     // caller whatever the values are, so nothing is read for it
     const bool dead = a.lens && t >= a.lens[b];
+    // Resident table (round 5): the entry's rows are CONTIGUOUS and ~88 % of them are live (key_map != 0), so they are streamed
+    // speculatively, all of them, without waiting for the key_map row -> ballot list -> row addresses chain: one dependent global round
+    // trip and two barriers less per word for 12 % more bytes, in a kernel that waits for latency at 12-15 % of the HBM rate.
+    // A dead row's logit stays at its masked value and it is left out of the running sum.
+    constexpr bool spec = SPEC;
+    if constexpr (SPEC) {
+        // batch padding (entry -2: 52 % of the B x T_w slots of a B = 60 Biaobei batch): key_map all zero -> every logit masked -> the
+        // softmax is uniform (expf(0) / (L * 1.0f) in the general path below), no sense carries weight, the context of a word past its
+        // utterance is zero.  Written directly: the general path spends 8 us of barriers and reductions per such word to get the same values.
+        if (r.special == -2 && dead) {   // (pinyin_map is all zero there: the forced-pronunciation rule cannot select anything either)
+            const float u = 1.0f / (float)L;
+            float* da = a.dict_attn + (long long)row * L;
+            for (int l = tid; l < L; l += S2PA_NTHR) da[l] = u;
+            for (int d = tid; d < a.D; d += S2PA_NTHR) a.wv[(long long)row * a.D + d] = 0.f;
+            if (tid < a.P) a.pron_attn[(long long)row * a.P + tid] = 0.f;
+            for (int c = tid; c < a.H; c += S2PA_NTHR) a.pron[(long long)row * a.H + c] = 0.f;
+            return;
+        }
+    }
+    int n = 0;
+    if constexpr (!SPEC) {
+        n = s2pa_list(sh, r, L, tid);
+        // a word past its utterance whose key_map row turned out all zero (the collater's padding; CHECKED here, the tensors are the caller's)
+        // and that is not forced to a sense: uniform weights, no sense carries weight, zero context — the same values the general path below
+        // computes with eight more barriers (52 % of the B x T_w slots of a B = 60 batch)
+        if (n == 0 && dead && pre.mod == 0) {
+            const float u = 1.0f / (float)L;
+            float* da = a.dict_attn + (long long)row * L;
+            for (int l = tid; l < L; l += S2PA_NTHR) da[l] = u;
+            for (int d = tid; d < a.D; d += S2PA_NTHR) a.wv[(long long)row * a.D + d] = 0.f;
+            if (tid < a.P) a.pron_attn[(long long)row * a.P + tid] = 0.f;
+            for (int c = tid; c < a.H; c += S2PA_NTHR) a.pron[(long long)row * a.H + c] = 0.f;
+            return;
+        }
+    }
     // ---- ONE streaming pass over the live rows: a wave takes RU listed rows at a time (12 independent 16-byte loads per lane
     // and row before the first reduction), computes their logits, and folds exp(logit - m) * value row into a running
     // weighted sum with a running maximum m (the online-softmax recurrence), so the value rows are not re-read after the
@@ -742,8 +841,98 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
         m_run = mn;
     };
 
+    if constexpr (!SPEC) S2_STAMP(1);
     constexpr int RV = RU / 2;   // rows folded together.  Row -> (wave, fold) assignment is the SAME with and without aliasing (chunk c
                                  // of RV rows goes to wave c % NW), so the two input forms give bit-identical results
+    if constexpr (SPEC) {
+        // ---- resident table, projected rows (D <= 256).  tools/s2pa_stamps.py (round 5): every workgroup of a B = 60 batch starts within
+        // 0.7 us and the kernel lasts as long as its slowest words; their time was the row stream, and the row stream was VALU ISSUE
+        // (6 waves per SIMD each spending ~75 instructions per row: a 64-lane dot product reduced by six shuffles, three full-precision
+        // exponentials per 2-row chunk), not HBM latency — requesting chunk c + 1 before reducing chunk c changed nothing.  Here a wave
+        // streams FOUR rows per step, 16 lanes per row: a lane holds PER 16-byte pieces of its row (3 at D = 192), the logit is reduced over
+        // 16 lanes by four row rotations, and every 16-lane group keeps its OWN running maximum / weighted sum over the rows it sees
+        // (no cross-group traffic inside the loop); the four groups of a wave meet once per word.  ~17 instructions per row.
+        static_assert(DM4 == 1 && (RU == 3 || RU == 4), "the projected table: D <= 256");
+        constexpr int PER = RU;                              // 16-byte pieces per lane (the RU parameter of this form): 3 for D <= 192, 4 for D <= 256
+        const int nrow = r.Lrow;
+        const int g = lane >> 4, c16 = lane & 15;            // row slot of this lane within a step, its first piece
+        f32x4 qg[PER];
+#pragma unroll
+        for (int pc = 0; pc < PER; ++pc) qg[pc] = (c16 + 16 * pc < D4) ? qp[c16 + 16 * pc] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ag[PER];
+#pragma unroll
+        for (int pc = 0; pc < PER; ++pc) ag[pc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mg = -3.0e38f;
+        int n_w = 0;
+        // the key_map row -> LDS; every logit starts at its masked / zero-vector value (the stream below overwrites the live ones)
+        f32x4 kq[PER], vq[PER];
+        float kmq = 0.f;
+        auto load_rows = [&](int i) {                        // rows i .. i + 3 of this wave
+            const int l = i + g;
+            const bool in = l < nrow;
+            kmq = in ? r.kmr[l] : 0.f;
+            const f32x4* kr = r.kb + (long long)(in ? l : 0) * D4;
+            const f32x4* vr = r.vb + (long long)(in ? l : 0) * D4;
+#pragma unroll
+            for (int pc = 0; pc < PER; ++pc) {
+                const bool ok = in && c16 + 16 * pc < D4;
+                kq[pc] = ok ? kr[c16 + 16 * pc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                vq[pc] = (ok && !dead) ? vr[c16 + 16 * pc] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        constexpr int STEP = S2PA_NW * 4;
+        int i = wave * 4;
+        if (i < nrow) load_rows(i);                          // in flight while the key_map row goes to LDS
+        for (int l = tid; l < L; l += S2PA_NTHR) {
+            const float kk = l < r.Lrow ? r.kmr[l] : (r.special == -1 ? 1.f : 0.f);
+            sh.km[l] = kk;
+            sh.lg[l] = kk == 0.f ? -1e9f : 0.f;
+        }
+        __syncthreads();
+        S2_STAMP(1);
+        while (i < nrow) {
+            float d = 0.f;
+#pragma unroll
+            for (int pc = 0; pc < PER; ++pc) d += kq[pc][0] * qg[pc][0] + kq[pc][1] * qg[pc][1] + kq[pc][2] * qg[pc][2] + kq[pc][3] * qg[pc][3];
+            // sum over the 16 lanes of the row (DPP row rotations: every lane ends with the full sum)
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));   // row_ror:8
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));   // row_ror:4
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));   // row_ror:2
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));   // row_ror:1
+            const int l = i + g;
+            const bool valid = l < nrow && kmq != 0.f;
+            if (valid && c16 == 0) sh.lg[l] = d;
+            n_w += __popcll(__ballot(valid && c16 == 0));
+            if (valid && !dead) {                            // (uniform per 16-lane group)
+                const float mn = fmaxf(mg, d);
+                const float sc = __expf(mg - mn), e = __expf(d - mn);
+#pragma unroll
+                for (int pc = 0; pc < PER; ++pc) ag[pc] = ag[pc] * sc + vq[pc] * e;
+                mg = mn;
+            }
+            i += STEP;
+            if (i < nrow) load_rows(i);                      // (latency is covered by the CU's other waves: up to 8 per SIMD)
+        }
+        // the wave's four row groups meet: (m, a) <- (max, a exp(m - max) + a' exp(m' - max)), partner 16 then 32 lanes away
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float mo = __shfl_xor(mg, o, 64);
+            const float mn = fmaxf(mg, mo);
+            const float sa = __expf(mg - mn), sb = __expf(mo - mn);   // (both groups empty: -3e38 - -3e38 = 0 -> 1 * 0 + 1 * 0)
+#pragma unroll
+            for (int pc = 0; pc < PER; ++pc)
+#pragma unroll
+                for (int x4 = 0; x4 < 4; ++x4) ag[pc][x4] = ag[pc][x4] * sa + __shfl_xor(ag[pc][x4], o, 64) * sb;
+            mg = mn;
+        }
+        m_run = mg;
+        if (g == 0) {
+#pragma unroll
+            for (int pc = 0; pc < PER; ++pc)
+                if (c16 + 16 * pc < D4) *(f32x4*)&sh.part[wave * sh.D + (c16 + 16 * pc) * 4] = ag[pc];
+        }
+        if (lane == 0) sh.pid[64 + wave] = n_w;              // live rows this wave saw (joined behind the barrier below)
+    } else {
     if (alias) {
         // two chunks (c, c + NW) of this wave in flight at once: 2 * RV rows = 12 independent 16-byte loads per lane
         for (int i = wave * RV; i < n; i += 2 * S2PA_NW * RV) {
@@ -805,11 +994,17 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
             if (!dead) fold_n(lg, v, min(n - i, RV), std::integral_constant<int, RV>{});
         }
     }
+    }   // (!SPEC)
+    if constexpr (!SPEC) {
 #pragma unroll
-    for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-        if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = acc[cc];
+        for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+            if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave * sh.D + (lane + 64 * cc) * 4] = acc[cc];
+    }
     if (lane == 0) sh.wmax[wave] = m_run;
+    S2_STAMP(2);
     __syncthreads();
+    S2_STAMP(3);
+    if (spec) n = (sh.pid[64] + sh.pid[65]) + (sh.pid[66] + sh.pid[67]);
     // softmax over l (all L logits: live, masked -1e9, zero-vector 0)
     float mx = -3.0e38f;
     for (int l = tid; l < L; l += S2PA_NTHR) mx = fmaxf(mx, sh.lg[l]);
@@ -823,6 +1018,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
     sm = s2pa_block_sum(sh, sm, tid);
     for (int l = tid; l < L; l += S2PA_NTHR) sh.lg[l] = sh.lg[l] / sm;
     __syncthreads();
+    S2_STAMP(4);
     if (n > 0 || dead) {
         // context = sum_w exp(m_w - mx) * partial_w / sm  (a wave that saw no row has m_w = -3e38: factor 0)
         float f[S2PA_NW];
@@ -831,7 +1027,7 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
         for (int d = tid; d < a.D; d += S2PA_NTHR) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d] * f[w];   // fixed order: reproducible
+            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w * sh.D + d] * f[w];   // fixed order: reproducible
             a.wv[(long long)row * a.D + d] = dead ? 0.f : sum;
         }
     } else {
@@ -841,32 +1037,56 @@ __global__ __launch_bounds__(S2PA_NTHR) void s2pa_kernel(const S2paArgs a) {
         f32x4 va[S2PA_DMAX4];
 #pragma unroll
         for (int cc = 0; cc < S2PA_DMAX4; ++cc) va[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int l = wave; l < n_val; l += S2PA_NW) {
-            const float w = sh.lg[l];
-            const f32x4* vr = r.vb + (long long)l * D4;
+        // four rows of a wave in flight at once (round 5: one row at a time was a chain of L_k / 4 dependent HBM round trips, 58 us for the
+        // true-EOS row of every shorter sentence in the collated tensors — the slowest workgroups of the tensor-API launch); summed in l order
+        for (int l0 = wave; l0 < n_val; l0 += 4 * S2PA_NW) {
+            f32x4 vv[4][S2PA_DMAX4];
 #pragma unroll
-            for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-                if (lane + 64 * cc < D4) va[cc] += vr[lane + 64 * cc] * w;
+            for (int j = 0; j < 4; ++j) {
+                const int l = l0 + j * S2PA_NW;
+                const f32x4* vr = r.vb + (long long)(l < n_val ? l : 0) * D4;
+#pragma unroll
+                for (int cc = 0; cc < S2PA_DMAX4; ++cc)
+                    vv[j][cc] = (l < n_val && lane + 64 * cc < D4) ? vr[lane + 64 * cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int l = l0 + j * S2PA_NW;
+                if (l >= n_val) break;
+                const float w = sh.lg[l];
+#pragma unroll
+                for (int cc = 0; cc < S2PA_DMAX4; ++cc) va[cc] += vv[j][cc] * w;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < S2PA_DMAX4; ++cc)
-            if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave][(lane + 64 * cc) * 4] = va[cc];
+            if (lane + 64 * cc < D4) *(f32x4*)&sh.part[wave * sh.D + (lane + 64 * cc) * 4] = va[cc];
         __syncthreads();
         for (int d = tid; d < a.D; d += S2PA_NTHR) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w][d];
+            for (int w = 0; w < S2PA_NW; ++w) sum += sh.part[w * sh.D + d];
             a.wv[(long long)row * a.D + d] = sum;
         }
     }
+    S2_STAMP(5);
     s2pa_tail(sh, a, pre, row, b, t, tid);
+    S2_STAMP(6);
 }
 
 hipError_t s2pa_launch(const S2paArgs& a, hipStream_t s) {
     if (a.L_k > S2PA_LMAX || a.D > 768 || (a.D & 3) || a.P > 64) return hipErrorInvalidValue;
-    if (a.D <= 256) hipLaunchKernelGGL((s2pa_kernel<1, S2PA_RU_P>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
-    else hipLaunchKernelGGL((s2pa_kernel<S2PA_DMAX4, S2PA_RU>), dim3(a.B * a.T_w), dim3(S2PA_NTHR), 0, s, a);
+    const size_t lds = s2pa_lds_bytes(a.L_k, a.D);   // <= 22.6 KB (L_k = 1024, D = 768): below the 64 KB that need no attribute
+    const dim3 g(a.B * a.T_w), t(S2PA_NTHR);
+    if (a.entry && a.D <= 192) {   // resident table of projected rows: the speculative 16-lanes-per-row stream, 3 pieces per lane
+        hipLaunchKernelGGL((s2pa_kernel<1, 3, true>), g, t, lds, s, a);
+    } else if (a.entry && a.D <= 256) {
+        hipLaunchKernelGGL((s2pa_kernel<1, 4, true>), g, t, lds, s, a);
+    } else {   // collated tensors — or, ablation builds (tune bit 6), a resident table of raw 768-wide gloss rows
+        if (a.D <= 256) hipLaunchKernelGGL((s2pa_kernel<1, S2PA_RU_P, false>), g, t, lds, s, a);
+        else hipLaunchKernelGGL((s2pa_kernel<S2PA_DMAX4, S2PA_RU, false>), g, t, lds, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -194,6 +194,16 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
 #pragma unroll
                 for (int m = 0; m < MT; ++m) xa[(u * MH + h + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
             }
+#if defined(RB_WINO_PROBE) && RB_WINO_PROBE >= 2   // TIMING PROBE ONLY (wrong results): the input transform of Winograd F(2,3) — one packed fp16 add per dword of every fragment
+            if constexpr (NKG >= 8) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    uint4& f = xa[(u * MH + h) & 1][m];
+                    asm volatile("v_pk_add_f16 %0, %0, %4\n\tv_pk_add_f16 %1, %1, %4\n\tv_pk_add_f16 %2, %2, %4\n\tv_pk_add_f16 %3, %3, %4"
+                                 : "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w) : "v"(0));
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m)

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // C = 32 (two k-groups per tap): the packs' zero padding to a multiple of four steps would be 25 / 12.5 / 8 % of the MFMAs at k = 3 / 7 / 11:
     // those configurations run the real steps only (rb2_contract, uniform exit at tap boundaries)
     constexpr bool REAL_STEPS = (NKG < 4);
+#ifdef RB_WINO_PROBE   // TIMING PROBE ONLY (wrong results): k = 3 at C >= 128 with 2/3 of the k-steps = the MFMA / LDS-read count of Winograd F(2,3)
+    const int S = (C >= 128 && Kr == 3) ? 2 * NKG : (REAL_STEPS ? Kr : R.Kp) * NKG;
+#else
     const int S = DTTS_DBG(p, 1) ? 0 : (REAL_STEPS ? Kr : R.Kp) * NKG;   // k-steps (packed taps are zero padded so that Kp * NKG % 4 == 0)
+#endif
     const bool last_rb = !PS || r + 1 == p.nrb;
     // what the epilogue does with the stage sum: one ResBlock per launch: p.mode; all of the stage's: write, accumulate.., finish
     const int mode = (!PS || p.nrb == 1 || r == 0) ? p.mode : (last_rb ? p.last_mode : 1);
@@ -251,7 +255,14 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5);
-                    const f32x4 v4 = {v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]};
+                    f32x4 v4 = {v[m][n][4 * q], v[m][n][4 * q + 1], v[m][n][4 * q + 2], v[m][n][4 * q + 3]};
+#if defined(RB_WINO_PROBE) && RB_WINO_PROBE >= 2   // (the output transform: one fp32 add per value, as two packed adds per four)
+                    if constexpr (C >= 128) {
+                        f32x2_t lo2 = {v4[0], v4[1]}, hi2 = {v4[2], v4[3]};
+                        asm volatile("v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %2" : "+v"(lo2), "+v"(hi2) : "v"(f32x2_t{0.f, 0.f}));
+                        v4 = f32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+                    }
+#endif
                     uint2 pk = act4<EL>(v4, 0.1f);
                     if constexpr (GUARD) n_ovf += counted ? ovf4(v4, 0.1f) : 0;
                     if constexpr (MASKED) {

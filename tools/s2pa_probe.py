@@ -15,7 +15,10 @@ from dict_tts_amd import abi, model, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4)
+ap.add_argument("--lib", default=None, help="path of the library build to load instead of the in-tree release library (A/B runs)")
 a = ap.parse_args()
+if a.lib:
+    abi.load_library(os.path.abspath(a.lib))
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 dev = torch.device("cuda", 0)
 m = model.PortaSpeech_dict(hparams={})
