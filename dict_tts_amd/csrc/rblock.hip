@@ -22,7 +22,9 @@
 
 namespace dtts {
 
-template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD>
+// TB (two LDS activation buffers, experiment of round 5): leaky_relu(x) and leaky_relu(xt) live in SEPARATE buffers, so the rewrite after a
+// contraction needs no write-after-read barrier (nobody reads the buffer it writes): two workgroup barriers per iteration instead of four.
+template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD, bool TB = false>
 __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void rblock_kernel(const RBlockParams p) {
     static_assert(WC * NT * 32 == C, "channel tiling must cover C");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -32,8 +34,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     constexpr int NKG = C / 16;
     constexpr int EP = C * 4 + 16;                 // fp32 staging row
     constexpr int F4 = C / 4, SROWS = WT * 32;
-    char* act = smem;
-    char* stage = smem + (size_t)(W + 2 * RB_GUARD) * PITCH;
+    constexpr size_t ACT_BYTES = (size_t)(W + 2 * RB_GUARD) * PITCH;
+    char* act = smem;                                    // leaky_relu(x)
+    char* act2 = TB ? smem + ACT_BYTES : smem;           // leaky_relu(xt): its own buffer (TB) or the same one, time-shared
+    char* stage = TB ? act2 + RB_GUARD * PITCH : smem + ACT_BYTES;   // epilogue transposition; TB: over the xt buffer's tile rows (dead after the last contraction, rewritten whole by the next tile; its guard bands stay zero)
 
     // per-thread coordinates; PS refreshes them through an opaque move at every tile (see the tile loop)
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             const int r = idx / (PITCH / 16), c = idx % (PITCH / 16);
             const int row = r < RB_GUARD ? r : W + r;
             *(uint4*)(act + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+            if constexpr (TB) *(uint4*)(act2 + row * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
         }
     };
     zero_guard_bands(tid);
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     int n_ovf = 0;
     // MASKED = false: a tile wholly inside its utterance (block-uniform, most tiles) — no row needs the zero select: 2 of the ~11 VALU
     // instructions per four values less, in the phase that is VALU-bound (LABNOTES round 4 (C))
-    auto write_act_impl = [&](const f32x16 (&v)[MT][NT], auto masked_tag) {
+    auto write_act_impl = [&](char* dst, const f32x16 (&v)[MT][NT], auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -268,21 +273,21 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     if constexpr (MASKED) {
                         if (!inb) pk = make_uint2(0, 0);
                     }
-                    *(uint2*)(act + (RB_GUARD + row) * PITCH + co * 2) = pk;
+                    *(uint2*)(dst + (RB_GUARD + row) * PITCH + co * 2) = pk;
                 }
         }
     };
-    auto write_act = [&](const f32x16 (&v)[MT][NT]) {
+    auto write_act = [&](char* dst, const f32x16 (&v)[MT][NT]) {
         if (DTTS_DBG(p, 8)) return;
-        if (all_inb) write_act_impl(v, std::false_type{});
-        else write_act_impl(v, std::true_type{});
+        if (all_inb) write_act_impl(dst, v, std::false_type{});
+        else write_act_impl(dst, v, std::true_type{});
     };
 
     uint4 ring[4][NT];
     f32x4 bb[NT][4];   // one live bias set
     rb_preload<NT>(ring, R.w1[0] + wlane, kg_stride);   // in flight during the first activation write
     load_bias(bb, R.b1[0]);
-    write_act(xr);
+    write_act(act, xr);
     __syncthreads();
 
     f32x16 acc[MT][NT];
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         } else
             rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, R.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
-        __syncthreads();               // every wave is done reading A
-        write_act(acc);                // xt (bf16, activated) overwrites it
+        if constexpr (!TB) __syncthreads();   // every wave is done reading A (TB: xt has its own buffer, last read before the previous barrier)
+        write_act(act2, acc);          // xt (16-bit, activated): overwrites A, or goes to its own buffer
         __syncthreads();
         // conv2 accumulates straight into the residual registers: x = x + b2 + W2 * xt
 #pragma unroll
@@ -318,14 +323,14 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
         if (it < 2) load_bias(bb, R.b1[it + 1]);
         if constexpr (REAL_STEPS) {
-            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, false>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, cinit);
+            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, false>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, cinit);
         } else
-            rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
+            rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, R.w1[it + 1] + wlane, kg_stride);
         if (PS && p.tile_ctr && last_rb && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
-        __syncthreads();               // every wave is done reading xt
+        if (!TB || it == 2) __syncthreads();   // every wave is done reading xt (TB: A is rewritten, not xt; the barrier stays in front of the epilogue)
         if (it < 2) {
-            write_act(xr);
+            write_act(act, xr);
             __syncthreads();
         }
     }
@@ -371,7 +376,8 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // the utterance zero = conv_post's zero padding) instead of going to HBM; the transposition buffer moves behind it
     constexpr int OP = C * 4;                      // otile row pitch (bytes)
     char* otile = smem;
-    char* estage = wav_now ? smem + (((size_t)TT * OP > (size_t)(W + 2 * RB_GUARD) * PITCH) ? (size_t)TT * OP : (size_t)(W + 2 * RB_GUARD) * PITCH) : stage;
+    // (TB: both activation buffers are dead in the epilogue; the staging rows follow the output tile inside them)
+    char* estage = wav_now ? smem + ((TB || (size_t)TT * OP > ACT_BYTES) ? (size_t)TT * OP : ACT_BYTES) : stage;
     char* stg = estage + (wt * 32) * EP + (wc * CW) * 4;                 // this wave's block of the staging buffer
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -480,16 +486,17 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     }   // (tiles of this workgroup)
 }
 
-template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD = false>
+template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD = false, bool TB = false>
 static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
     const int H = 6 * (p.K - 1), TT = W - 2 * H;
     if (TT < 32) return hipErrorInvalidValue;
-    size_t lds = (size_t)(W + 2 * RB_GUARD) * PITCH + (size_t)WT * 32 * EP;
+    constexpr size_t ACT = (size_t)(W + 2 * RB_GUARD) * PITCH;
+    size_t lds = TB ? std::max(2 * ACT, ACT + (size_t)RB_GUARD * PITCH + (size_t)WT * 32 * EP) : ACT + (size_t)WT * 32 * EP;   // TB: the staging rows lie over the xt buffer
     int TTo = TT;
     if (p.wav) {   // fused conv_post (7 taps): the fp32 output tile may be larger than the activation tile it replaces
         if (C != 32 || (p.nrb == 1 && p.mode != 2) || !p.post_w || !p.post_b) return hipErrorInvalidValue;
-        lds = std::max((size_t)TT * C * 4, (size_t)(W + 2 * RB_GUARD) * PITCH) + (size_t)WT * 32 * EP;
+        lds = TB ? std::max(2 * ACT, (size_t)TT * C * 4 + (size_t)WT * 32 * EP) : std::max((size_t)TT * C * 4, ACT) + (size_t)WT * 32 * EP;
         TTo = TT - 6;
     }
     RBlockParams q = p;
@@ -497,9 +504,9 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if constexpr (EL == EL_F16 && !GUARD) {
-        if (p.ovf) return rb_launch_cfg<C, MT, NT, WT, WC, EL, PS, true>(p, stream);
+        if (p.ovf) return rb_launch_cfg<C, MT, NT, WT, WC, EL, PS, true, TB>(p, stream);
     }
-    auto kern = rblock_kernel<C, MT, NT, WT, WC, EL, PS, GUARD>;
+    auto kern = rblock_kernel<C, MT, NT, WT, WC, EL, PS, GUARD, TB>;
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;
@@ -584,6 +591,9 @@ static hipError_t rb_launch_el(const RBlockParams& p, int C, hipStream_t stream)
     // (experiment, tune bit 7) C = 32 without the fused conv_post: two phase-shifted groups per workgroup (rblock2.hip)
 #ifdef DTTS_ABLATE   // (rblock2.hip is compiled into the ablation library only)
     if (p.pingpong && rblock2_supported(C, p.K, p.wav != nullptr) && !few(512)) return rblock2_launch(p, C, stream);
+#endif
+#if defined(RB_TB32)   // experiment: two activation buffers at C = 32, k >= 7: 768-row tiles (MT = 3), two barriers per iteration instead of four
+    if (C == 32 && rb32 && p.K >= 7 && !few(768)) return rb_launch_cfg<32, 3, 1, 8, 1, EL, 1, false, true>(p, stream);
 #endif
 #if defined(RB_X32) && RB_X32 == 1   // experiment: 12 waves (3 per SIMD) over 1152 rows at C = 32, k >= 7
     if (C == 32 && rb32 && p.K >= 7 && !few(1152)) {   // (with the fused conv_post the 1152-row output tile does not fit the LDS: falls through)

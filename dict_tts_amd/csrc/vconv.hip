@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
 // "hh/h": 7e-5 waveform RMS when ups.1 alone runs this way (gate 1e-4, 5.3e-5 with three products everywhere).  fp16 hi saturates at
 // 65504 and lo carries the rest, so the pair represents |a| up to 1.3e5.
 template <int MT, int NT, int WT, int WC, int CK, bool X3, bool H2 = false>
-__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? 4 : ((VC_SB1 && NT == 1) ? 3 : 2)) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
+__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : 4) : ((VC_SB1 && NT == 1) ? 3 : 2)) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
     static_assert(!H2 || X3, "H2 is a variant of the fp32-input path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
@@ -474,10 +474,18 @@ hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
     const int ci = p.C_in_pad, co = p.C_out_pad;
     if ((p.gate_H || p.split) && !p.xf) return hipErrorInvalidValue;   // the WaveNet epilogue exists on the split-operand path only
     if (co % 256 == 0) {
+        // ups.1 (256 -> 8 x 128 channels, two C_in chunks): 64-row tiles, three workgroups per CU instead of two 128-row ones — its workgroups
+        // have half the contraction per epilogue of ups.0's, and a third resident workgroup covers more of the staging / epilogue phases:
+        // 762 -> 735 us, same bits (round 5; ups.0 with four chunks loses on the same form: 183 -> 323 us, and keeps the 128-row tiles)
+        if (p.xf && p.small_tiles && !p.h2 && ci == 256) return vlaunch_x<2, 2, 1, 4, 128, true>(p, stream);
         if (ci % 128 == 0) return vlaunch<4, 2, 1, 4, 128>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
         return vlaunch<4, 2, 1, 4, 32>(p, stream);
     }
+    // the decoder WaveNet layers (gate / res-skip epilogue; 192 -> 384 channels, k = 5 / 1): 64-row tiles, four workgroups per CU.  On 128-row
+    // tiles a B = 60 batch was 1,080 workgroups for 768 slots (two rounds for 1.4 rounds of work) and one sentence 12 workgroups:
+    // decode 1.165 -> 1.117 ms at B = 60, 0.515 -> 0.446 ms at B = 1 (round 5, same contraction order: same bits)
+    if (p.xf && (p.gate_H || p.split) && co % 128 == 0 && ci % 64 == 0) return vlaunch_x<2, 1, 1, 4, 64, true>(p, stream);
     if (p.xf && p.small_tiles && co % 128 == 0 && ci % 128 == 0) return vlaunch_x<2, 1, 1, 4, 128, true>(p, stream);
     if (p.xf && p.small_tiles && co % 64 == 0 && co % 128 && ci % 64 == 0) return vlaunch_x<2, 1, 2, 2, 64, true>(p, stream);
     if (co % 128 == 0) {
