@@ -514,7 +514,10 @@ constexpr int S2PA_LMAX = 1024, S2PA_DMAX4 = 3;  // D <= 768 (3 float4 per lane)
 #ifndef S2PA_RU_P
 #define S2PA_RU_P 4
 #endif
-constexpr int S2PA_NW = 4, S2PA_RU = 4;           // waves per workgroup; gloss rows a wave keeps in flight (3 x 16 B per lane each)
+#ifndef S2PA_RU_T
+#define S2PA_RU_T 4
+#endif
+constexpr int S2PA_NW = 4, S2PA_RU = S2PA_RU_T;           // waves per workgroup; gloss rows a wave keeps in flight (3 x 16 B per lane each)
 constexpr int S2PA_NTHR = S2PA_NW * 64;
 
 // The workgroup's LDS, carved from DYNAMIC shared memory sized for the launch's L_k and row width D (round 5): the static form was sized for
@@ -758,7 +761,10 @@ __global__ __launch_bounds__(S2PA_NTHR, DM4 == 1 ? S2PA_WPE : S2PA_WPE3) void s2
     // workgroup i -> word (b, t) = (i % B, i / B): position-major.  The kernel lasts as long as its longest words (tools/s2pa_stamps.py), and in
     // the collated tensors those are the BOS rows (t = 0: key_map all ones, L_k "live" zero vectors — 130 rows against ~36 for a dictionary
     // word): they are dispatched FIRST and stream beside everything else instead of starting in the second round of workgroups.
-    const int b = blockIdx.x % a.B, t = blockIdx.x / a.B;
+    // ... and so are the LAST padded rows (t = T_w - 1: key_map all ones for every sentence, dataset_utils.py:288-300), which follow them at once:
+    // dispatched last, these 60 words started at 29 us and ended the launch at 70 us (round 5 stamps)
+    const int b = blockIdx.x % a.B, tq = blockIdx.x / a.B;
+    const int t = tq == 0 ? 0 : (tq == 1 ? a.T_w - 1 : tq - 1);
     const int row = b * a.T_w + t;
     const int L = a.L_k, D4 = a.D / 4;
     const S2paRow r = s2pa_row(a, row);

@@ -355,6 +355,9 @@ static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t strea
     static const bool small_ok = [] { const char* e = ablate_env("DTTS_VP_SMALL"); return !e || atoi(e) != 0; }();
     auto tiles_of = [&](int tt) { return (long long)p.B * ((p.T + (tt - (p.K - 1)) - 1) / (tt - (p.K - 1))); };
     if (C == 256) {
+#ifdef VP_FORCE64    // experiment: 64-row tiles at C = 256 whatever the tile count
+        return vpair_launch_tt<256, 64, EL>(p, stream);
+#endif
         if (small_ok && 2 * tiles_of(128) <= vpair_cus()) return vpair_launch_tt<256, 64, EL>(p, stream);
         // 128-row tiles, or 96-row ones where only those leave room for TWO workgroups per CU (one workgroup = one wave per SIMD exposes
         // every latency of the memory phases: k = 7 with dilation 5, k = 11 with dilation 3)
@@ -365,6 +368,9 @@ static hipError_t vpair_launch_el(const VPairParams& p, int C, hipStream_t strea
     // 256-row tiles while two workgroups still fit a CU's 160 KB of LDS (all but k = 11 with dilation 5)
     const size_t rows256 = (size_t)256 + (size_t)p.dil * (p.K - 1) + std::max(p.dil + 1, 8);
     const bool big = (rows256 * (128 * 2 + 16) + (size_t)(3 * p.B + 2) * sizeof(int)) * 2 <= 160 * 1024;
+#ifdef VP_FORCE128   // experiment (small grids: long form, B = 1): 128-row tiles at C = 128 whatever the tile count
+    return vpair_launch_tt<128, 128, EL>(p, stream);
+#endif
     if (small_ok && 2 * tiles_of(256) <= vpair_cus()) return vpair_launch_tt<128, 128, EL>(p, stream);
 #ifdef VP_NT2   // experiment: 2 x 2 waves, two co-tiles per wave
     if (big) return vpair_launch_tt<128, 256, EL, false, 2>(p, stream);

@@ -106,16 +106,20 @@ typedef struct dtts_config {
     int32_t debug_redzone;            /* testing aid: 1 = memory-safety mode — every workspace buffer and weight pack sits between 4 KiB red
                                          zones, workspaces are filled with 0xFF (NaN) before each forward; dtts_debug_check verifies the zones */
     int32_t tune_flags;               /* A/B switches of tuning experiments (tools/ab_*.sh); 0 = the measured defaults.  The library never
-                                         reads the process environment: arithmetic and layout follow this struct alone.  Bits that change
-                                         ARITHMETIC: 8 prior flow launch by launch on exact-fp32 kernels, 10 fp32 g_pre_net, 11 fp32 flow conditioning,
-                                         13 two-product fp16 ups.1 (eats waveform margin), 16 strided g_pre_net, 17 fp32 MFMA instead of the
-                                         three-piece bf16 products; LAYOUT: 6 raw (unprojected) dictionary table; SCHEDULE only: 0 conv_post as its
-                                         own kernel, 1 upsamplers without the zero-tap skip, 2 static tile assignment, 3 no whole-ResBlock fusion
-                                         at C >= 128, 4 per-launch timer events, 5 128-row tiles for the narrow upsamplers, 7 two-group phase-shifted ResBlock kernel at
-                                         C = 32 (rblock2.hip), 9 all ResBlocks of a C <= 64 stage in one launch (less HBM traffic, not faster), 12 the first two ResBlocks of the
-                                         C = 32 stage in one launch (neutral), 14 512-row tiles for every k at C = 64.  (Builds made with
-                                         -DDTTS_ABLATE — `make ablate`, tools/ab_*.sh — additionally OR the DTTS_TUNE environment variable in and
-                                         honour a few more schedule-only variables; the release library has no such code.) */
+                                         reads the process environment: arithmetic and layout follow this struct alone.
+                                         The RELEASE library honours exactly the bits that have a parity / bit-identity test behind them and
+                                         refuses every other one (dtts_create: DTTS_E_INVAL):
+                                           8  (arithmetic) prior flow launch by launch on the exact-fp32 kernels
+                                           9  (schedule)   all ResBlocks of a C <= 64 stage in one launch (less HBM traffic, not faster)
+                                           12 (schedule)   the first two ResBlocks of the C = 32 stage in one launch (neutral)
+                                           13 (arithmetic) two-product fp16 ups.1 (eats waveform margin)
+                                           14 (schedule)   512-row tiles for every k at C = 64
+                                         Builds made with -DDTTS_ABLATE (`make ablate`, tools/ab_tune.sh) additionally carry the untested
+                                         experiments — 0 conv_post as its own kernel, 1 upsamplers without the zero-tap skip, 2 static tile
+                                         assignment, 3 no whole-ResBlock fusion at C >= 128, 4 per-launch timer events, 5 128-row tiles for the
+                                         narrow upsamplers, 6 raw (unprojected) dictionary table, 7 two-group phase-shifted ResBlock kernel
+                                         (rblock2.hip), 10 fp32 g_pre_net, 11 fp32 flow conditioning, 16 strided g_pre_net, 17 fp32 MFMA instead of the
+                                         three-piece bf16 products — OR the DTTS_TUNE environment variable in and honour a few schedule-only variables. */
 } dtts_config;
 
 /* Fill *cfg with the Biaobei Dict-TTS + HifiGAN defaults listed above. */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] alone (1000 characters, ~5k mel frames, B=1, teacher-forced 5 frames/char): text->mel and vocoder times, for
-`rocprofv3 --kernel-trace` + tools/timeline.py.  usage: python tools/longform_bench.py [reps]"""
+`rocprofv3 --kernel-trace` + tools/timeline.py.  usage: python tools/longform_bench.py [reps] [--lib build/x/variant.so]"""
 import os
 import sys
 import time
@@ -9,9 +9,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 
-from dict_tts_amd import model, synth, vocoder
+from dict_tts_amd import abi, model, synth, vocoder
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+if "--lib" in sys.argv:   # A/B runs: another build of the library, selected by path
+    i = sys.argv.index("--lib")
+    abi.load_library(os.path.abspath(sys.argv[i + 1]))
+    del sys.argv[i:i + 2]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 sd = synth.dict_tts_state_dict(1234)
 m = model.PortaSpeech_dict(hparams={})

@@ -55,3 +55,10 @@ for sel, lab in ((live, "live words"), (~live, "BOS / padding words")):
         print(f"   {nm:70s} {dlt.mean():6.2f} {np.percentile(dlt, 50):6.2f} {np.percentile(dlt, 95):6.2f}")
     tot = (a[sel, 6] - a[sel, 0]) * 0.01
     print(f"   {'whole workgroup':70s} {tot.mean():6.2f} {np.percentile(tot, 50):6.2f} {np.percentile(tot, 95):6.2f}")
+# the slowest workgroups: who they are and where their time went
+tot = (a[:, 6] - a[:, 0]) * 0.01
+order = np.argsort(-(a[:, 6] - t0))[:8]
+print("-- the 8 workgroups that finish last (block, start us, end us, phases us):")
+for i in order:
+    ph = " ".join(f"{(a[i, k + 1] - a[i, k]) * 0.01:5.1f}" for k in range(6))
+    print(f"   block {i:5d}  start {(a[i, 0] - t0) * 0.01:6.2f}  end {(a[i, 6] - t0) * 0.01:6.2f}   {ph}")
