@@ -318,7 +318,13 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : 4) : ((VC_SB1 &
                             g += *(const f32x4*)(c + p.gate_H + co);
                         }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = tanhf(o[e]) * (1.f / (1.f + expf(-g[e])));
+                        for (int e = 0; e < 4; ++e) {
+                            // tanh(a) * sigmoid(g) = (1 - 2 / (e^{2a} + 1)) / (1 + e^{-g}) on the hardware exp2 / rcp (a few ulp; the form the fused
+                            // prior flow uses, flowstack.hip): 8.5 M gates per layer at B = 60, ~45 -> ~12 instructions each.  Saturates
+                            // cleanly (e^{2a} = inf -> 1, 0 -> -1)
+                            const float ea = __expf(2.f * o[e]), eg = __expf(-g[e]);
+                            o[e] = (1.f - 2.f * __frcp_rn(ea + 1.f)) * __frcp_rn(1.f + eg);
+                        }
                     } else if (p.gbias) {
                         o += *(const f32x4*)(p.gbias + co);
                     }
