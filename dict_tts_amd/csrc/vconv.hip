@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : 4) : ((VC_SB1 &
             // padding, no per-access compare, one VGPR of address per load.  U loads in flight per thread and batch: the narrow 64-row
             // upsampler tiles (8-9 pieces per thread) take ONE batch = one exposed HBM round trip per tile instead of three.
             constexpr int U = MT <= 2 ? VC_U_SMALL : 4, PIECES = CK / 4, RS = 256 / PIECES;
-            static_assert(256 % PIECES == 0, "a thread keeps its column");
+            // (PIECES = 48 at CK = 192: five rows per pass, the last 16 threads of the workgroup stage nothing)
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
             const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xfb, 0, len * p.ldx * 4, 0x00020000);
             const int c = tid % PIECES, r0 = tid / PIECES;
             const bool c_ok = ci0 + c * 4 < p.C_in;
             const int voff0 = ((in0 + r0) * p.ldx + ci0 + c * 4) * 4, vstep = RS * p.ldx * 4;
-            const int nk = (rows - r0 + RS - 1) / RS;   // rows this thread stages
+            const int nk = tid < RS * PIECES ? (rows - r0 + RS - 1) / RS : 0;   // rows this thread stages
             for (int kb = 0; kb < nk; kb += U) {
                 u32x4 v[U];
 #pragma unroll
@@ -488,6 +488,9 @@ hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
         if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
         return vlaunch<4, 2, 1, 4, 32>(p, stream);
     }
+#ifdef VC_DEC_CK192   // experiment: the whole C_in = 192 of a decoder WaveNet layer as ONE chunk (one staging + barrier per tile instead of three)
+    if (p.xf && (p.gate_H || p.split) && co % 128 == 0 && ci == 192 && (VC_DEC_CK192 >= 2 || p.K == 1)) return vlaunch_x<2, 1, 1, 4, 192, true>(p, stream);
+#endif
     // the decoder WaveNet layers (gate / res-skip epilogue; 192 -> 384 channels, k = 5 / 1): 64-row tiles, four workgroups per CU.  On 128-row
     // tiles a B = 60 batch was 1,080 workgroups for 768 slots (two rounds for 1.4 rounds of work) and one sentence 12 workgroups:
     // decode 1.165 -> 1.117 ms at B = 60, 0.515 -> 0.446 ms at B = 1 (round 5, same contraction order: same bits)
