@@ -442,6 +442,48 @@ def test_run_inference_two_stream_pipeline_equals_serial(acoustic, voc, tmp_path
 
 
 @pytest.mark.gpu
+def test_two_stream_harness_redoes_an_overflowed_batch_and_the_one_in_flight(voc_sd):
+    """the always-on fp16 overflow detector inside the PIPELINED harness (infer._iter_results, pipeline=True): batch 1 of four carries a mel
+    far outside the stated range (x 3e6) and overflows the fp16 ResBlocks.  Its waveform comes back finite and equal to the bf16x3 vocoder's
+    (AUTO redid it), batch 2 — already in flight in fp16 when the overflow was noticed — is redone too, batches 0 / 2 / 3 equal what the
+    serial loop produces, and with an explicit 'f16' vocoder the same run raises instead of handing a poisoned waveform on."""
+    from dict_tts_amd import infer, vocoder
+    cfg = synth.hifigan_config()
+    mels = [T(np.stack([synth.random_mel(40 + k, 48, f"pipe{k}")])).cuda() for k in range(4)]
+    mels[1] = mels[1] * 3e6
+
+    class FakeModel:   # the harness only needs mel_out / mel_lens / pron_attn from the acoustic model
+        def __call__(self, *a, **kw):
+            k = FakeModel.k
+            FakeModel.k += 1
+            return {"mel_out": mels[k], "mel_lens": torch.tensor([48], dtype=torch.int32, device="cuda"), "pron_attn": torch.zeros(1, 3, 2)}
+    batches = [{"word_tokens": torch.ones(1, 3, dtype=torch.int64), "keys": None, "values": None, "key_map": None, "pinyin": torch.zeros(1, 3, 2, dtype=torch.int64),
+                "pinyin_map": None} for _ in range(4)]
+    x3 = vocoder.HifiGAN(state_dict=voc_sd, config=cfg, precision="bf16x3")
+    f16 = vocoder.HifiGAN(state_dict=voc_sd, config=cfg, precision="f16")
+    want = []
+    for k in range(4):
+        v = x3 if k == 1 else f16
+        want.append(v.to_int16(v.forward_batch(mels[k], torch.tensor([48], dtype=torch.int32)), torch.tensor([48], dtype=torch.int32)).cpu().numpy()[0])
+    torch.cuda.synchronize()
+    assert not f16.overflowed()
+    import warnings
+    FakeModel.k = 0
+    auto = vocoder.HifiGAN(state_dict=voc_sd, config=cfg)
+    with warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        got = [w[0] for _, _, w in infer._iter_results(FakeModel(), auto, batches, pipeline=True)]
+    assert auto.precision == abi.VOC_BF16X3 and any("overflowed" in str(w.message) for w in ws)
+    assert len(got) == 4 and all(np.isfinite(g.astype(np.float64)).all() for g in got)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])        # fp16 before the overflow; the overflowed batch redone in bf16x3
+    for k in (2, 3):                                                                  # after the switch: bf16x3, within the int16 step of the fp16 result
+        assert np.abs(got[k].astype(np.int32) - want[k].astype(np.int32)).max() <= 16, k
+    FakeModel.k = 0
+    with pytest.raises(abi.DttsError, match="overflowed"):
+        list(infer._iter_results(FakeModel(), f16, batches, pipeline=True))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("norm", [False, True])
 def test_device_int16_conversion_equals_reference_rule(voc, norm):
     """dtts_wav_to_int16 == utils/audio.py:11-16 per utterance over its own valid samples (wav / max|wav| if norm;
