@@ -37,6 +37,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_FRAME_VOCODER = 614_105_088   # 2*MAC of HifiGanGenerator per mel frame
 FLOP_PER_FRAME_DECODER = 4_691_968     # A8-A10 per (padded) mel frame
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
+DATA_CEILING_F16_TFLOPS = 1670.0       # what a register-resident v_mfma_f32_32x32x16_f16 loop sustains on this chip with NON-ZERO fp16 operands, two waves
+                                       # per SIMD (tools/micro/mfma_peak: 1,669.8; 2,342-2,485 with all-zero operands; profiles/r05_*_mfma_ceiling.txt)
 PEAK_HBM_GBS = 8000.0
 DUR_BIAS = 3.09                        # exp(softplus(3.09)) - 1 ~= 22 frames per word
 N_TEST = 200                           # Biaobei test rows (label_set0.csv)
@@ -713,6 +715,10 @@ def main():
             "ranks_seen": seen, "distinct_devices": (len({(r["device_index"], r["device_uuid"]) for r in seen}) if seen else 1),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "data_ceiling": {"peak": DATA_CEILING_F16_TFLOPS, "frac": achieved / DATA_CEILING_F16_TFLOPS,
+                                          "what": "the matrix rate a bare MFMA loop sustains with data-carrying fp16 operands (the chip throttles MFMA issue with "
+                                                  "operand toggling: 1.67 PF against 2.34-2.48 PF with zeros; tools/micro/mfma_peak, profiles/*_mfma_ceiling.txt) — "
+                                                  "context for `frac`, which stays priced against the 2.5 PF dense peak"},
                          "kernel": "dtts::vconv_kernel<*> + dtts::vpair_kernel<256|128,*> + dtts::rblock_kernel<*> (every HifiGAN convolution; "
                                    f"{conv_launches // max(n_timed, 1)} launches/forward)",
                          "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
@@ -724,7 +730,8 @@ def main():
         }
         if iso is not None and iso[0] > 0:
             ia = FLOP_PER_FRAME_VOCODER * iso[2] / (iso[0] * 1e-3) / 1e12
-            out["roofline"]["isolated"] = {"achieved": ia, "frac": ia / PEAK_BF16_TFLOPS, "kernel_ms_per_forward": iso[0], "launches": iso[1]}
+            out["roofline"]["isolated"] = {"achieved": ia, "frac": ia / PEAK_BF16_TFLOPS, "frac_of_data_ceiling": ia / DATA_CEILING_F16_TFLOPS,
+                                           "kernel_ms_per_forward": iso[0], "launches": iso[1]}
         if side:
             out["side"] = side
         if modes:
