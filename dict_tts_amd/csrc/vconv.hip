@@ -479,6 +479,9 @@ static hipError_t vlaunch(const VConvParams& p, hipStream_t stream) {
 hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
     const int ci = p.C_in_pad, co = p.C_out_pad;
     if ((p.gate_H || p.split) && !p.xf) return hipErrorInvalidValue;   // the WaveNet epilogue exists on the split-operand path only
+    // the prior flow's conditioning convolution (192 -> 2,048 channels over T_mel / 4 = 111-185 rows per utterance): 64-row tiles, three workgroups
+    // per CU (128-row tiles: 960 workgroups for 512 slots at B = 60, 8 at B = 1): decode -24 us / -8 us (round 5)
+    if (p.xf && !p.gate_H && !p.split && !p.small_tiles && co % 256 == 0 && ci == 192) return vlaunch_x<2, 2, 1, 4, 64, true>(p, stream);
     if (co % 256 == 0) {
         // ups.1 (256 -> 8 x 128 channels, two C_in chunks): 64-row tiles, three workgroups per CU instead of two 128-row ones — its workgroups
         // have half the contraction per epilogue of ups.0's, and a third resident workgroup covers more of the staging / epilogue phases:
@@ -503,6 +506,12 @@ hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
         return vlaunch<4, 1, 1, 4, 32>(p, stream);
     }
     if (co % 64 == 0) {
+        // the last res_skip layer of the decoder WaveNet (192 -> 192, 1x1): 128-row tiles instead of 256 (decode -17 us / -5 us; round 5)
+        if (p.xf && (p.gate_H || p.split) && ci % 64 == 0) return vlaunch_x<2, 1, 2, 2, 64, true>(p, stream);
+        // the strided g_pre_net (768 -> 192 channels over T_mel / 4 rows as a 3-tap convolution over 4-frame groups): 128-row tiles and
+        // 128-channel chunks — on the generic form it was ONE 256-row tile per utterance (T_mel / 4 = 111-185 rows: half of it empty) walking
+        // twelve 64-channel chunks in sequence: 63 us at B = 1.  decode -25 us (B = 60), -19 us (B = 1); round 5
+        if (p.xf && p.in_half && ci % 128 == 0) return vlaunch_x<2, 1, 2, 2, 128, true>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 1, 2, 2, 64>(p, stream);
         return vlaunch<4, 1, 2, 2, 32>(p, stream);
     }
