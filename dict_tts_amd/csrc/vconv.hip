@@ -44,7 +44,10 @@ __device__ __forceinline__ unsigned vf2bf(float f) {  // round-to-nearest-even f
 // "hh/h": 7e-5 waveform RMS when ups.1 alone runs this way (gate 1e-4, 5.3e-5 with three products everywhere).  fp16 hi saturates at
 // 65504 and lo carries the rest, so the pair represents |a| up to 1.3e5.
 template <int MT, int NT, int WT, int WC, int CK, bool X3, bool H2 = false>
-__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : 4) : ((VC_SB1 && NT == 1) ? 3 : 2)) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
+#ifndef VC_WPE_DEC
+#define VC_WPE_DEC 4
+#endif
+__global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : (CK == 64 && WC == 4 ? VC_WPE_DEC : 4)) : ((VC_SB1 && NT == 1) ? 3 : 2)) : (NT == 1 ? 3 : 2)) void vconv_kernel(const VConvParams p) {
     static_assert(!H2 || X3, "H2 is a variant of the fp32-input path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCH = CK * 2 + 16;
