@@ -490,6 +490,7 @@ hipError_t vconv_launch(const VConvParams& p, hipStream_t stream) {
         // have half the contraction per epilogue of ups.0's, and a third resident workgroup covers more of the staging / epilogue phases:
         // 762 -> 735 us, same bits (round 5; ups.0 with four chunks loses on the same form: 183 -> 323 us, and keeps the 128-row tiles)
         if (p.xf && p.small_tiles && !p.h2 && ci == 256) return vlaunch_x<2, 2, 1, 4, 128, true>(p, stream);
+        // (conv_pre — one 128-channel chunk, 720 workgroups for 512 slots — on the same form: 94.8 -> 92.5 us, within noise; left on 128-row tiles)
         if (ci % 128 == 0) return vlaunch<4, 2, 1, 4, 128>(p, stream);
         if (ci % 64 == 0) return vlaunch<4, 2, 1, 4, 64>(p, stream);
         return vlaunch<4, 2, 1, 4, 32>(p, stream);
