@@ -22,6 +22,22 @@
 
 namespace dtts {
 
+#ifdef RB_STAMP   // per-phase clock stamps (tools/rb_stamps.py; a variant build, never the release library): sums over the tiles of every workgroup,
+                  // wave 0 (table 0) and the last wave (table 1), one row per (C, k): s_memrealtime ticks of 10 ns
+__device__ unsigned long long rb_stamps[2][12][16];
+extern "C" __attribute__((visibility("default"))) int dtts_debug_rb_stamps(unsigned long long* host, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(rb_stamps), sizeof(rb_stamps));
+    if (e == hipSuccess && reset) {
+        static unsigned long long z[2][12][16];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(rb_stamps), z, sizeof z);
+    }
+    return (int)e;
+}
+#define RB_T(k) do { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); tq[k] += _n - t_last; t_last = _n; } while (0)
+#else
+#define RB_T(k)
+#endif
+
 // TB (two LDS activation buffers, experiment of round 5): leaky_relu(x) and leaky_relu(xt) live in SEPARATE buffers, so the rewrite after a
 // contraction needs no write-after-read barrier (nobody reads the buffer it writes): two workgroup barriers per iteration instead of four.
 template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD, bool TB = false>
@@ -166,6 +182,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // work items of a workgroup: (tile, ResBlock r) — r runs over the launch's p.nrb ResBlocks on the SAME tile before the next tile
     int r = 0;
 
+#ifdef RB_STAMP
+    unsigned long long tq[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
     for (;;) {
     if constexpr (PS) {
@@ -285,10 +305,13 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 
     uint4 ring[4][NT];
     f32x4 bb[NT][4];   // one live bias set
+    RB_T(10);                                            // (tile bookkeeping, and — the first tile — the wait for x)
     rb_preload<NT>(ring, R.w1[0] + wlane, kg_stride);   // in flight during the first activation write
     load_bias(bb, R.b1[0]);
     write_act(act, xr);
+    RB_T(0);
     __syncthreads();
+    RB_T(1);
 
     f32x16 acc[MT][NT];
 #pragma unroll 1
@@ -309,9 +332,13 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         } else
             rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, R.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
+        RB_T(2);
         if constexpr (!TB) __syncthreads();   // every wave is done reading A (TB: xt has its own buffer, last read before the previous barrier)
+        RB_T(3);
         write_act(act2, acc);          // xt (16-bit, activated): overwrites A, or goes to its own buffer
+        RB_T(4);
         __syncthreads();
+        RB_T(5);
         // conv2 accumulates straight into the residual registers: x = x + b2 + W2 * xt
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -328,10 +355,14 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, R.w1[it + 1] + wlane, kg_stride);
         if (PS && p.tile_ctr && last_rb && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
+        RB_T(6);
         if (!TB || it == 2) __syncthreads();   // every wave is done reading xt (TB: A is rewritten, not xt; the barrier stays in front of the epilogue)
+        RB_T(7);
         if (it < 2) {
             write_act(act, xr);
+            RB_T(0);
             __syncthreads();
+            RB_T(1);
         }
     }
 
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             if (mode >= 1) sold[m][u] = p.nrb > 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, 0)
                                                   : __builtin_amdgcn_raw_buffer_load_b128(rs_s, eoff(m, u), 0, VP_LD_AUX);
         }
+    RB_T(12);                                            // (epilogue: plan + stage-sum loads issued)
     // fused conv_post: the stage output leaky_relu(xs / num_kernels) stays in LDS as an fp32 tile ([TT rows][C], rows outside
     // the utterance zero = conv_post's zero padding) instead of going to HBM; the transposition buffer moves behind it
     constexpr int OP = C * 4;                      // otile row pitch (bytes)
@@ -396,6 +428,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        RB_T(13);                                        // (slab: accumulators -> staging rows, next tile's loads issued)
 #pragma unroll
         for (int u = 0; u < NRD; ++u) {
             const int off = eoff(m, u);
@@ -429,6 +462,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                               // slab m + 1 reuses this wave's staging block
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        RB_T(14);                                        // (slab: rows read back, + stage sum, stored)
     }
     if constexpr (C == 32) if (wav_now) {   // (the launcher rejects p.wav for other widths)
         // ---- wav[t] = tanh(b + sum_{tap, c} w[c][tap] * otile[t + tap - 3][c])   (conv_post + tanh, hifigan.py:139-141) in exact fp32:
@@ -466,6 +500,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         }
     }
     }   // (epilogue)
+    RB_T(8);                                             // epilogue (+ the fused conv_post)
+#ifdef RB_STAMP
+    tq[11] += 1;
+#endif
     if constexpr (GUARD) {
         if (n_ovf) atomicAdd(p.ovf, (unsigned long long)n_ovf);
     }
@@ -484,6 +522,15 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     len = lenn;
     t0 = t0n;
     }   // (tiles of this workgroup)
+#ifdef RB_STAMP
+    {
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0 && (w == 0 || w == WT * WC - 1)) {
+            const int slot = (C == 32 ? 0 : C == 64 ? 1 : C == 128 ? 2 : 3) * 3 + (p.K == 3 ? 0 : p.K == 7 ? 1 : 2);
+            for (int k = 0; k < 16; ++k) atomicAdd(&rb_stamps[w == 0 ? 0 : 1][slot][k], tq[k]);
+        }
+    }
+#endif
 }
 
 template <int C, int MT, int NT, int WT, int WC, int EL, int PS, bool GUARD = false, bool TB = false>
