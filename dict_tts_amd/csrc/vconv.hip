@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, X3 ? (MT <= 2 ? (NT == 2 ? 3 : (CK == 64 && WC
         if (ci0) __syncthreads();
         if constexpr (X3) {   // fp32 in: leaky_relu, bf16 hi / lo split, two LDS tiles; 4 channels per 16 B load
 #ifndef VC_U_SMALL
-#define VC_U_SMALL 4
+#define VC_U_SMALL 9   // (LABNOTES (L): measured with -DVC_U_SMALL=9, and the default was left at 4 until round 5 (S))
 #endif
             // A thread keeps its 4-channel piece and walks the rows in steps of 256 / PIECES.  Buffer loads over the utterance's rows
             // [0, len): a row outside it (t < 0 wraps to a huge unsigned offset, t >= len exceeds num_records) returns zeros = the zero
