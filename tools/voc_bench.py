@@ -17,6 +17,7 @@ ap.add_argument("--B", type=int, default=60)
 ap.add_argument("--T", type=int, default=740)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--precision", default="f16")
+ap.add_argument("--uniform", action="store_true", help="every utterance T frames long (tile-count experiments)")
 ap.add_argument("--tune", type=int, default=0, help="dtts_config.tune_flags (A/B switches, include/dicttts_hip.h)")
 ap.add_argument("--lib", default=None, help="path of the library build to load instead of the in-tree release library (A/B runs: nothing is copied over it)")
 a = ap.parse_args()
@@ -29,6 +30,8 @@ voc.ctx.timer_enable(abi.TIMER_VOC_CONV)
 rng = np.random.default_rng(0)
 lens = np.clip(rng.normal(364, 110, a.B), 120, a.T).astype(np.int32)
 lens[0] = a.T
+if a.uniform:
+    lens[:] = a.T
 mel = torch.from_numpy(np.clip(rng.normal(-3, 1.2, (a.B, a.T, 80)), -6, 1.5).astype(np.float32)).cuda()
 lens_d = torch.from_numpy(lens).cuda()
 for _ in range(2):
