@@ -236,11 +236,15 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the vocoder on the text->mel stream (default: vocoder of batch i on a second HIP stream, "
                          "overlapping text->mel of batch i+1; every batch is still fully processed inside the timed region)")
+    ap.add_argument("--lib", default=None, help="path of a library build to load instead of the in-tree release library (same-box A/B runs "
+                                                "with the ablation build; the headline is always measured on the release library)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     from dict_tts_amd import abi, model, synth, vocoder
+    if args.lib:
+        abi.load_library(os.path.abspath(args.lib))
     from dict_tts_amd.shard import gather_mels, n_steps, ranks_seen, shard_indices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

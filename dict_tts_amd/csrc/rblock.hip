@@ -474,28 +474,58 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         for (int k = 0; k < PK; ++k) wq[k] = *(const f32x4*)(p.post_w + k * C + q8 * 4);
         const float pb = p.post_b[0];
         float* wb = p.wav + brow;
-        for (int o0 = 0; o0 < TTo; o0 += THREADS / 8) {
-            const int o = o0 + rr;                                     // output index within the tile: otile rows o .. o + PK - 1
-            float a = 0.f;
-            if (o < TTo) {
+        // each 8-lane group slides over PR consecutive outputs (PR + PK - 1 row reads instead of PR * PK; PR odd: neighbouring groups start
+        // 128 B apart modulo the 256 B of the LDS banks); every output is still summed tap by tap in the order of the one-output form
+        constexpr int PR = 3;
+        for (int o0 = 0; o0 < TTo; o0 += (THREADS / 8) * PR) {
+            const int ob = o0 + rr * PR;                               // first output of this group: otile rows ob .. ob + PR + PK - 2
+            float a[PR];
 #pragma unroll
-                for (int k = 0; k < PK; ++k) {
-                    const f32x4 v = *(const f32x4*)(otile + (size_t)(o + k) * OP + q8 * 16);
-                    a += v[0] * wq[k][0] + v[1] * wq[k][1] + v[2] * wq[k][2] + v[3] * wq[k][3];
+            for (int i = 0; i < PR; ++i) a[i] = 0.f;
+            if (ob < TTo) {
+#pragma unroll
+                for (int j = 0; j < PR + PK - 1; ++j) {
+                    const int row = ob + j < TTo + PK - 1 ? ob + j : TTo + PK - 2;   // (rows past the tile feed discarded outputs only)
+                    const f32x4 v = *(const f32x4*)(otile + (size_t)row * OP + q8 * 16);
+#pragma unroll
+                    for (int i = 0; i < PR; ++i) {
+                        const int k = j - i;
+                        if (k >= 0 && k < PK) {   // explicit operations: the same rounding sequence for every output, whatever its place in a group / tile
+                            const float d = __builtin_fmaf(v[3], wq[k][3], __builtin_fmaf(v[2], wq[k][2], __builtin_fmaf(v[1], wq[k][1], __fmul_rn(v[0], wq[k][0]))));
+                            a[i] = __fadd_rn(a[i], d);
+                        }
+                    }
                 }
             }
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 4, 64);
-            const int t = t0 + PH + o;
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                a[i] += __shfl_xor(a[i], 1, 64);
+                a[i] += __shfl_xor(a[i], 2, 64);
+                a[i] += __shfl_xor(a[i], 4, 64);
+            }
             // ALWAYS-ON overflow detector (every instantiation, every call): an fp16 operand that overflowed anywhere upstream is +-inf, every
             // sum it enters is inf / NaN from there on (the fp32 residual stream never recovers), so it arrives HERE as a non-finite
             // pre-tanh value.  tanh would turn +-inf into a plausible +-1: the sample is poisoned with NaN instead and counted.
-            const float pre = a + pb;
-            const bool nonfin = !(__builtin_fabsf(pre) <= 3.0e38f);
-            if (q8 == 0 && o < TTo && t < len) {
-                wb[t] = nonfin ? __builtin_nanf("") : tanhf(pre);
-                if (nonfin && p.bad) atomicAdd(p.bad, 1u);   // (never on a healthy call)
+            // tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware exp2 / rcp, evaluated by every lane (libm's tanhf ran its ~45 instructions for
+            // the one live lane in eight): absolute error <= 3e-7 (1 / 100 of an int16 step), saturates correctly at +-1.
+            float pre[PR], th[PR];
+            bool nf = false;
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                pre[i] = a[i] + pb;
+                th[i] = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(__fadd_rn(__builtin_amdgcn_exp2f(pre[i] * 2.885390081777927f), 1.f)), 1.f);   // (2 log2 e)
+            }
+            if (q8 == 0) {
+#pragma unroll
+                for (int i = 0; i < PR; ++i) {
+                    const int o = ob + i, t = t0 + PH + o;
+                    const bool nonfin = !(__builtin_fabsf(pre[i]) <= 3.0e38f);
+                    if (o < TTo && t < len) {
+                        wb[t] = nonfin ? __builtin_nanf("") : th[i];
+                        nf |= nonfin;
+                    }
+                }
+                if (nf && p.bad) atomicAdd(p.bad, 1u);   // (never on a healthy call)
             }
         }
     }
@@ -579,7 +609,7 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     }
     const int per_cu = std::max(1, std::min({(int)(160 * 1024 / lds), 2048 / THREADS, THREADS <= 256 ? 2 : 1}));
     const long long max_tiles = (long long)p.B * ((p.T + TTo - 1) / TTo);
-    const int grid = (int)std::min<long long>((long long)cus * per_cu, max_tiles);
+    const int grid = (int)std::min<long long>((long long)std::max(1, cus - cu_reserve()) * per_cu, max_tiles);
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, q);
     return hipGetLastError();

@@ -14,6 +14,13 @@ inline const char* ablate_env(const char* name) {
 #endif
 }
 
+// experiment (ablation builds): the persistent ResBlock grids leave DTTS_CU_RESERVE compute units' worth of workgroup slots free, so that
+// the other stream's text->mel kernels find a slot at any time instead of only at the vocoder's launch boundaries
+inline int cu_reserve() {
+    static const int v = [] { const char* e = ablate_env("DTTS_CU_RESERVE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 // dtts_config.tune_flags (include/dicttts_hip.h).  The RELEASE library honours only the bits that have a parity / bit-identity test behind
 // them (tests/test_gpu_parity.py): 8 prior flow launch by launch on the exact-fp32 kernels, 9 all ResBlocks of a C <= 64 stage in one launch,
 // 12 the first two ResBlocks of the C = 32 stage in one launch, 13 two-product fp16 ups.1, 14 512-row tiles for every k at C = 64.  Every

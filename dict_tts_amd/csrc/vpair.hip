@@ -326,7 +326,7 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     }
     const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), (CC == 128 && TT == 128 && WT == 1) ? 3 : 2));
     const long long max_tiles = (long long)p.B * ((p.T + TTe - 1) / TTe);
-    const int grid = (int)std::min<long long>((long long)cus * per_cu, max_tiles);
+    const int grid = (int)std::min<long long>((long long)std::max(1, cus - cu_reserve()) * per_cu, max_tiles);
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, q);
     return hipGetLastError();
