@@ -46,7 +46,7 @@ dt = (time.perf_counter() - t0) / a.iters
 ms, n = voc.ctx.timer_read(abi.TIMER_VOC_CONV)
 frames = int(lens.sum())
 import hashlib
-print(f"wav md5 {hashlib.md5(wav.cpu().numpy().tobytes()).hexdigest()[:12]}  sum|wav| {float(wav.abs().double().sum()):.6f}")   # bit-identity across builds
+print(f"wav md5 {hashlib.md5(wav.cpu().numpy().tobytes()).hexdigest()[:12]}  sum|wav| {float(wav.abs().double().sum()):.6f}  nonfinite-counter {int(voc.ctx.vocoder_nonfinite())}")   # bit-identity across builds
 print(f"frames {frames}  wall {dt * 1e3:.2f} ms/forward  conv-kernel {ms / a.iters:.2f} ms/forward  "
       f"{614105088 * frames / (ms / a.iters * 1e-3) / 1e12:.1f} TFLOP/s  ({frames / dt:.0f} frames/s vocoder-only)")
 if os.environ.get("DTTS_CALIB"):
