@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase clock stamps of the whole-ResBlock kernels (a variant build with -DRB_STAMP: tools/build_variant.sh rbst "-DRB_STAMP" rblock.hip).
-usage: python tools/rb_stamps.py build/x/rbst.so  -> per (C, k): microseconds per tile and phase, wave 0 and the workgroup's last wave"""
+usage: python tools/rb_stamps.py build/x/rbst.so [tune_flags]  -> per (C, k): microseconds per tile and phase, wave 0 and the workgroup's last wave"""
 import ctypes as C
 import os
 import sys
@@ -12,8 +12,9 @@ import torch
 from dict_tts_amd import abi, synth, vocoder
 
 lib = abi.load_library(os.path.abspath(sys.argv[1]))
+tune = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # dtts_config.tune_flags of the vocoder context
 T_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
-voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config=synth.hifigan_config(), precision="f16")
+voc = vocoder.HifiGAN(state_dict={k: T_(v) for k, v in synth.hifigan_state_dict(1234).items()}, config={**synth.hifigan_config(), "dtts_tune_flags": tune}, precision="f16")
 rng = np.random.default_rng(0)
 B, T = 60, 740
 lens = np.clip(rng.normal(364, 110, B), 120, T).astype(np.int32)
