@@ -164,8 +164,8 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
 // MH > 1: the wave owns MH * MT row tiles, processed as MH passes of MT tiles per weight fragment (pass h covers rows
 // h * MT * 32 ...): a weight fragment is fetched once per step and used for MH * MT MFMAs, while only 2 * MT activation
 // fragments are live at a time.
-template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1>
-__device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[2][MT],
+template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1, bool XA1 = false>
+__device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[XA1 ? 1 : 2][MT],
                                          const char* act, const uint4* wpf, int xb, int dilP, int g) {
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
     constexpr int KGS = (NKG / 2) * 64;               // uint4 elements between consecutive steps (= NCT * 64, NCT = NKG / 2)
@@ -178,6 +178,7 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
 #pragma unroll
                 for (int n = 0; n < NT; ++n) ring[(u + 3) & 3][n] = wpf[u * KGS + n * 64];
             }
+            int xa1_off = 0;
             {   // activation fragments of the next (step, pass)
                 int off;
                 if (h + 1 < MH) {
@@ -191,8 +192,10 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
                     const int un = u + 1;                        // step within the group of TU taps
                     off = xb + (un / NKG) * dilP + (un % NKG) * 32;
                 }
+                if constexpr (!XA1) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xa[(u * MH + h + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+                    for (int m = 0; m < MT; ++m) xa[(u * MH + h + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+                } else xa1_off = off;
             }
 #if defined(RB_WINO_PROBE) && RB_WINO_PROBE >= 2   // TIMING PROBE ONLY (wrong results): the input transform of Winograd F(2,3) — one packed fp16 add per dword of every fragment
             if constexpr (NKG >= 8) {
@@ -209,13 +212,15 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    if constexpr (CINIT) {
-                        if (u == 0) {
-                            acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[(u * MH + h) & 1][m], cinit[n]);
-                            continue;
+                    if (CINIT && u == 0) acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[XA1 ? 0 : (u * MH + h) & 1][m], cinit[n]);
+                    else acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[XA1 ? 0 : (u * MH + h) & 1][m], acc[h * MT + m][n]);
+                    if constexpr (XA1) {   // row tile m's fragment of the next step, behind the MFMAs that read the current one (NT == 1 here)
+                        if (n == NT - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            xa[0][m] = *(const uint4*)(act + xa1_off + m * 32 * PITCH);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    acc[h * MT + m][n] = mfma16<EL>(ring[u][n], xa[(u * MH + h) & 1][m], acc[h * MT + m][n]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -227,14 +232,14 @@ __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x1
 // ds_read_b128, global_load_dwordx4 and ~4 address instructions.  Weight fragments run 3 steps ahead (register ring),
 // activation fragments 1 step ahead.  The packed weights carry >= 4 zero steps of slack, the LDS tile >= one extra tap
 // of guard rows, so the prefetches past the last step need no clamping.  CINIT: acc = cinit + W * act (acc not read).
-template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT = false, int MH = 1>
+template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT = false, int MH = 1, bool XA1 = false>
 __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&ring)[4][NT], const char* act, int xrow0, const uint4* w,
                                             int S, int dilP, int kg_stride_unused, const f32x16 (*cinit)[NT] = nullptr) {
     constexpr int TU = (NKG >= 4) ? 1 : 4 / NKG;      // taps per group of 4 steps
     constexpr int GPT = (NKG >= 4) ? NKG / 4 : 1;     // groups per tap
     constexpr int KGS = (NKG / 2) * 64;
     static_assert(MH == 1 || (MH & 1) == 0, "the activation double buffer alternates per pass: MH must be 1 or even");
-    uint4 xa[2][MT];
+    uint4 xa[XA1 ? 1 : 2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
     const uint4* wpf = w + 3 * KGS;                   // prefetch pointer, 3 steps ahead
@@ -243,7 +248,7 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&
     int s0 = 0;
     if constexpr (CINIT) {
         if (S > 0) {
-            rb_group<EL, MT, NT, NKG, PITCH, true, MH>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
+            rb_group<EL, MT, NT, NKG, PITCH, true, MH, XA1>(acc, *cinit, ring, xa, act, wpf, xb, dilP, 0);
             s0 = 4;
             wpf += 4 * KGS;
             if constexpr (NKG >= 4) {
@@ -263,7 +268,7 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[MH * MT][NT], uint4 (&
     }
     for (; s0 < S; s0 += 4) {
         const f32x16(&dummy)[NT] = *(const f32x16(*)[NT])acc[0];
-        rb_group<EL, MT, NT, NKG, PITCH, false, MH>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
+        rb_group<EL, MT, NT, NKG, PITCH, false, MH, XA1>(acc, dummy, ring, xa, act, wpf, xb, dilP, g);
         wpf += 4 * KGS;
         if constexpr (NKG >= 4) {
             if (++g == GPT) {
@@ -289,8 +294,8 @@ __device__ __forceinline__ void rb2_preload(uint4 (&ring)[RD][NT], const uint4* 
         for (int n = 0; n < NT; ++n) ring[s][n] = w[(size_t)s * kgs + n * 64];
 }
 
-template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool FIRST, bool CINIT>
-__device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[RD][NT], uint4 (&xa)[2][MT],
+template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool FIRST, bool CINIT, bool XA1 = false>
+__device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[RD][NT], uint4 (&xa)[XA1 ? 1 : 2][MT],
                                           const char* act, const uint4* wpf, int xb, int dilP, int left) {   // left: steps still to do (> 0)
     constexpr int KGS = (NKG / 2) * 64;
     static_assert(RD % NKG == 0 && RD % 2 == 0, "a ring turn covers whole taps");
@@ -299,8 +304,8 @@ __device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&
         if (u && u % NKG == 0 && u >= left) return true;                // (uniform) the last tap is done
 #pragma unroll
         for (int n = 0; n < NT; ++n) ring[(u + RD - 1) % RD][n] = wpf[u * KGS + n * 64];
-        {
-            const int off = xb + ((u + 1) / NKG) * dilP + ((u + 1) % NKG) * 32;
+        const int off = xb + ((u + 1) / NKG) * dilP + ((u + 1) % NKG) * 32;
+        if constexpr (!XA1) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) xa[(u + 1) & 1][m] = *(const uint4*)(act + off + m * 32 * PITCH);
         }
@@ -309,13 +314,15 @@ __device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                if constexpr (FIRST && CINIT) {
-                    if (u == 0) {
-                        acc[m][n] = mfma16<EL>(ring[u][n], xa[u & 1][m], cinit[n]);
-                        continue;
+                if (FIRST && CINIT && u == 0) acc[m][n] = mfma16<EL>(ring[u][n], xa[XA1 ? 0 : u & 1][m], cinit[n]);
+                else acc[m][n] = mfma16<EL>(ring[u][n], xa[XA1 ? 0 : u & 1][m], acc[m][n]);
+                if constexpr (XA1) {   // row tile m's fragment of the next step, behind the MFMAs that read the current one
+                    if (n == NT - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        xa[0][m] = *(const uint4*)(act + off + m * 32 * PITCH);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                acc[m][n] = mfma16<EL>(ring[u][n], xa[u & 1][m], acc[m][n]);
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -323,20 +330,20 @@ __device__ __forceinline__ bool rb2_group(f32x16 (&acc)[MT][NT], const f32x16 (&
 }
 
 // acc (+)= W * act over the S = K * NKG real steps; ring holds steps 0 .. RD - 2 on entry (rb2_preload).  CINIT: acc = cinit + W * act.
-template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool CINIT>
+template <int EL, int MT, int NT, int NKG, int PITCH, int RD, bool CINIT, bool XA1 = false>
 __device__ __forceinline__ void rb2_contract(f32x16 (&acc)[MT][NT], uint4 (&ring)[RD][NT], const char* act, int xrow0, const uint4* w, int S,
                                              int dilP, const f32x16 (&cinit)[NT]) {
     constexpr int KGS = (NKG / 2) * 64;
-    uint4 xa[2][MT];
+    uint4 xa[XA1 ? 1 : 2][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xa[0][m] = *(const uint4*)(act + xrow0 + m * 32 * PITCH);
     const uint4* wpf = w + (RD - 1) * KGS;
     int xb = xrow0;
-    if (rb2_group<EL, MT, NT, NKG, PITCH, RD, true, CINIT>(acc, cinit, ring, xa, act, wpf, xb, dilP, S)) return;
+    if (rb2_group<EL, MT, NT, NKG, PITCH, RD, true, CINIT, XA1>(acc, cinit, ring, xa, act, wpf, xb, dilP, S)) return;
     for (int left = S - RD;; left -= RD) {
         wpf += RD * KGS;
         xb += (RD / NKG) * dilP;
-        if (rb2_group<EL, MT, NT, NKG, PITCH, RD, false, CINIT>(acc, cinit, ring, xa, act, wpf, xb, dilP, left)) return;
+        if (rb2_group<EL, MT, NT, NKG, PITCH, RD, false, CINIT, XA1>(acc, cinit, ring, xa, act, wpf, xb, dilP, left)) return;
     }
 }
 

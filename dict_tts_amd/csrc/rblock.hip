@@ -48,6 +48,20 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     constexpr int W = 32 * MT * WT;
     constexpr int PITCH = C * 2 + 16;
     constexpr int NKG = C / 16;
+    // ONE activation-fragment set (rb_common.h: XA1) in the 640-row C = 64 instantiation: with the double buffer it sat at 256 VGPRs with 13 of them
+    // spilled; the single set (a row tile's next fragment is read right behind the MFMAs that consumed the current one and lands while the other row
+    // tiles' MFMAs run) takes 249 and spills nothing.  Same instruction order per accumulator: same bits; -0.7 % on the vocoder (LABNOTES round 5 (Y)).
+#ifndef RB_XA1
+#define RB_XA1 1
+#endif
+#ifndef RB_XA1_ALL
+#define RB_XA1_ALL 1   // every C >= 64 instantiation (C = 32: neutral / +2 %, keeps the double buffer)
+#endif
+    constexpr bool XA1 = RB_XA1 && ((C == 64 && MT == 5) || (RB_XA1_ALL && C >= 64));
+#ifndef RB_XA1_32
+#define RB_XA1_32 1
+#endif
+    constexpr bool XA1_32 = RB_XA1_32 != 0;   // the same in the C = 32 contraction (rb2_contract)
     constexpr int EP = C * 4 + 16;                 // fp32 staging row
     constexpr int F4 = C / 4, SROWS = WT * 32;
     constexpr size_t ACT_BYTES = (size_t)(W + 2 * RB_GUARD) * PITCH;
@@ -327,10 +341,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
         load_bias(bb, R.b2[it]);       // lands while conv1 runs
         const int d = R.dil[it];
         if constexpr (REAL_STEPS) {
-            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, cinit);
-            else rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, 0, R.w1[it] + wlane, 0, 0, kg_stride, &cinit);
+            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, true, XA1_32>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, cinit);
+            else rb_contract<EL, MT, NT, NKG, PITCH, true, 1, XA1>(acc, ring, act, 0, R.w1[it] + wlane, 0, 0, kg_stride, &cinit);
         } else
-            rb_contract<EL, MT, NT, NKG, PITCH, true>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
+            rb_contract<EL, MT, NT, NKG, PITCH, true, 1, XA1>(acc, ring, act, xlane - ((Kr - 1) / 2) * d * PITCH, R.w1[it] + wlane, S, d * PITCH, kg_stride, &cinit);
         rb_preload<NT>(ring, R.w2[it] + wlane, kg_stride);   // next conv's first weights fly during barrier + write
         RB_T(2);
         if constexpr (!TB) __syncthreads();   // every wave is done reading A (TB: xt has its own buffer, last read before the previous barrier)
@@ -350,9 +364,9 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     for (int e = 0; e < 4; ++e) xr[m][n][4 * q + e] += bb[n][q][e];
         if (it < 2) load_bias(bb, R.b1[it + 1]);
         if constexpr (REAL_STEPS) {
-            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, false>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, cinit);
+            if (S) rb2_contract<EL, MT, NT, NKG, PITCH, 4, false, XA1_32>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, cinit);
         } else
-            rb_contract<EL, MT, NT, NKG, PITCH>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
+            rb_contract<EL, MT, NT, NKG, PITCH, false, 1, XA1>(xr, ring, act2, xlane - ((Kr - 1) / 2) * PITCH, R.w2[it] + wlane, S, PITCH, kg_stride);
         if (it < 2) rb_preload<NT>(ring, R.w1[it + 1] + wlane, kg_stride);
         if (PS && p.tile_ctr && last_rb && it == 2 && tid == 0) pre[3 * p.B + 1] = G + (int)claim;   // the claimed tile, for everyone (read behind the barrier)
         RB_T(6);

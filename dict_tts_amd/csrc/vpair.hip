@@ -30,6 +30,10 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
     constexpr int WC = 4 / WT, TW = TT / WT;     // waves over the output channels; rows of a time-wave
     constexpr int MT = (TW == 192 || TW == 96) ? 3 : (TW == 64 ? 2 : 4), NT = C / (32 * WC), MH = TW / (32 * MT), MTT = MT * MH;   // TW = 192: two passes of 3 row tiles
     constexpr int PITCH = C * 2 + 16, NKG = C / 16, NCT = C / 32;
+#ifndef VP_XA1
+#define VP_XA1 1
+#endif
+    constexpr bool XA1 = VP_XA1 != 0;   // one activation-fragment set in the contractions (rb_common.h)
     constexpr int EP = C * 4 + 16, F4 = C / 4;
     static_assert(NCT == WC * NT && (NT == 1 || MH == 1) && WT * WC == 4, "4 waves: WT over time x WC over the output channels");
     const int tid0 = threadIdx.x;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
     };
     if (NT == 1) load_b2();   // lands while c1 runs; at C = 256 its 32 registers do not fit beside c1's (spills): fetched after c1 there
     const int xlane = (wt * TW + (lane & 31)) * PITCH + (lane >> 5) * 16;
-    rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
+    rb_contract<EL, MT, NT, NKG, PITCH, true, MH, XA1>(acc, ring, smem, xlane, p.w1 + wlane, S, p.dil * PITCH, 0, &cinit);
     if (NT != 1) load_b2();
     rb_preload<NT>(ring, p.w2 + wlane, NCT * 64);
     VP_STAMP(2);
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) cinit[n][4 * q + e] = bb[n][q][e];
-    rb_contract<EL, MT, NT, NKG, PITCH, true, MH>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
+    rb_contract<EL, MT, NT, NKG, PITCH, true, MH, XA1>(acc, ring, smem, xlane, p.w2 + wlane, S, PITCH, 0, &cinit);
     VP_STAMP(4);
     __syncthreads();   // the xt tile is dead: the staging buffer of the epilogue aliases it
 
