@@ -164,6 +164,10 @@ __device__ __forceinline__ void rb_preload(uint4 (&ring)[4][NT], const uint4* w,
 // MH > 1: the wave owns MH * MT row tiles, processed as MH passes of MT tiles per weight fragment (pass h covers rows
 // h * MT * 32 ...): a weight fragment is fetched once per step and used for MH * MT MFMAs, while only 2 * MT activation
 // fragments are live at a time.
+// XA1 (round 5 (Y); what every vpair / rblock instantiation uses): ONE set of activation fragments.  Instead of reading the next (step, pass)'s MT fragments in one
+// burst at the top of a step (the double buffer), row tile m's next fragment is read right behind the MFMAs that consumed the current one and lands while the other
+// row tiles' MFMAs run: eight waves' bursts no longer queue on the CU's LDS pipe in front of the matrix pipe (-1.5 ... -5.9 % per kernel), MT * 4 registers less.
+// The scheduling barriers around the read keep it where it is written (+0.4 % without them).  (The line "(NT == 1 here)" below: the read follows the LAST co-tile's MFMA.)
 template <int EL, int MT, int NT, int NKG, int PITCH, bool CINIT, int MH = 1, bool XA1 = false>
 __device__ __forceinline__ void rb_group(f32x16 (&acc)[MH * MT][NT], const f32x16 (&cinit)[NT], uint4 (&ring)[4][NT], uint4 (&xa)[XA1 ? 1 : 2][MT],
                                          const char* act, const uint4* wpf, int xb, int dilP, int g) {
