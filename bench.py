@@ -245,7 +245,7 @@ def main():
     from dict_tts_amd import abi, model, synth, vocoder
     if args.lib:
         abi.load_library(os.path.abspath(args.lib))
-    from dict_tts_amd.shard import gather_mels, n_steps, ranks_seen, shard_indices
+    from dict_tts_amd.shard import exchange_shapes, gather_mels, n_steps, ranks_seen, shard_indices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -359,6 +359,7 @@ def main():
         cur = torch.cuda.current_stream()
         stream = cur.cuda_stream
         mel = lens = None
+        T_mel = 0
         if hb is not None:
             B, T_w, L_k, P_ = hb["B"], hb["T_w"], hb["L_k"], hb["P"]
             if mode == "tensors":
@@ -373,19 +374,29 @@ def main():
                     d = dev_ids[k % len(batches)]
                 T_mel = mdl.ctx.text2mel_encode_ids(ptr(d["word_tokens"]), ptr(d["entry_ids"]), ptr(d["pron_modified"]), None,
                                                     B, T_w, L_k, P_, stream)
+        shapes = None
+        if gather_on:   # (B, T_mel) is known on the host as soon as encode has returned: the 2-int exchange starts HERE, on the communication
+            # stream, and is read only after this batch's decode + vocoder have been enqueued (every rank enters, with or without a batch)
+            with torch.cuda.stream(comm_stream):
+                shapes = exchange_shapes(hb["B"] if hb is not None else 0, T_mel, dist, comm_device="cpu" if one_dev else None)
+        if hb is not None:
             mel = torch.empty(B, T_mel, 80, device=dev)
             mdl.ctx.text2mel_decode(None, mel.data_ptr(), stream)     # z_p = NULL: the prior sample is drawn on the device
             lens = torch.empty(B, dtype=torch.int32, device=dev)
             mdl.ctx.fetch(abi.OUT_MEL_LENS, lens.data_ptr(), stream)
-        if gather_on:   # every rank enters, with or without a batch (dict_tts_amd/shard.py)
+
+        def gather_step():   # the padded all-gather of this step's mels: behind the decoder on the communication stream; the host has
+            # nothing left to enqueue for this batch when it reads the (long finished) shape exchange
             comm_stream.wait_stream(cur)
             with torch.cuda.stream(comm_stream):
-                mel_all, lens_all, meta = gather_mels(mel, lens, dist, comm_device="cpu" if one_dev else None)
+                mel_all, lens_all, meta = gather_mels(mel, lens, dist, comm_device="cpu" if one_dev else None, shapes=shapes)
             gather_info["calls"] += 1
             gather_info["last_meta"] = meta.tolist()
             if mel_all is not None and mel is not None:
                 mel.record_stream(comm_stream)
         if hb is None:
+            if gather_on:
+                gather_step()
             return None, None, 0
         out_stream = voc_stream if pipelined else cur
         if pipelined:
@@ -406,8 +417,8 @@ def main():
         if pipelined:
             mel.record_stream(voc_stream)
             lens.record_stream(voc_stream)
-        if gather_on:
-            cur.wait_stream(comm_stream)
+        if gather_on:   # (the next step's text->mel does not wait for it: gathers are ordered among themselves on the communication stream)
+            gather_step()
         state["last"] = (mel, lens, wav, hb, T_mel)
         return lens, wav, T_mel
 

@@ -692,14 +692,17 @@ int build_acoustic(dtts_ctx* h) {
 //   worst case (a PROOF when it stays below 65504):  u_out[co] = |b[co]| + sum_ci u_in[ci] * sum_k |w[co][ci][k]|   (transposed convolutions:
 //     the largest output phase), leaky_relu does not grow a bound, the residual adds, the stage output is the mean of its ResBlocks;
 //   RMS estimate (NOT a proof: independent, zero-mean terms):  m_out[co] = b^2 + sum_ci m_in[ci] * sum_k w^2, leaky_relu halves it.
-// Both are affine in M (M^2 for the second moments), so two evaluations give coefficients for any mel range: dtts_vocoder_fp16_bound.
+// Every (operand, channel) bound is affine in M (M^2 for the second moments): a_q + b_q * M with a_q = the value at M = 0 and b_q = value(1) -
+// value(0), both >= 0.  The PEAK over channels is a maximum of affine functions — convex, so a secant through the peaks at M = 0 and 1
+// would UNDERestimate it beyond M = 1 (a bias-dominated channel sets both peaks while another channel's gain term overtakes it at
+// M = 6: ADVICE r5).  Reported instead: max_q a_q + M * max_q b_q >= max_q (a_q + b_q M) for every M >= 0 — looser, but a bound.
 // For real checkpoints the worst case is astronomically loose (it compounds sum|w| ~ 10-40 per convolution over 6 convolutions per
 // ResBlock): it proves small-gain generators only.  Everything else runs fp16 under the always-on detector (conv_post epilogue).
 bool vocoder_fp16_analysis(dtts_ctx* h, Need& need) {
     const dtts_config& c = h->cfg;
     const std::string v = "vocoder.";
     const int nk = c.n_resblock_kernels;
-    double peak_wc[2] = {0, 0}, peak_m2[2] = {0, 0};   // [pass]: pass 0 = M = 0 (the bias part), pass 1 = M = 1
+    std::vector<double> pt_wc[2], pt_m2[2];   // [pass][operand point x channel, in traversal order]: pass 0 = M = 0 (the bias part), pass 1 = M = 1
     for (int pass = 0; pass < 2; ++pass) {
         const double M = pass;
         auto conv = [&](const std::string& base, const std::vector<double>& uin, const std::vector<double>& min, std::vector<double>& uout,
@@ -761,15 +764,15 @@ bool vocoder_fp16_analysis(dtts_ctx* h, Need& need) {
                 const std::string rb = v + "resblocks." + std::to_string(i * nk + j);
                 for (int mth = 0; mth < 3; ++mth) {
                     for (int q = 0; q < co_n; ++q) {
-                        peak_wc[pass] = std::max(peak_wc[pass], x[q]);           // fp16 operand: leaky_relu(x)
-                        peak_m2[pass] = std::max(peak_m2[pass], xm[q]);
+                        pt_wc[pass].push_back(x[q]);                             // fp16 operand: leaky_relu(x) (and, iterations 1 / 2, the stored fp16 stream)
+                        pt_m2[pass].push_back(xm[q]);
                         xa[q] = x[q];
                         xam[q] = 0.505 * xm[q];
                     }
                     if (!conv(rb + ".convs1." + std::to_string(mth), xa, xam, xt, xtm)) return false;
                     for (int q = 0; q < co_n; ++q) {
-                        peak_wc[pass] = std::max(peak_wc[pass], xt[q]);          // fp16 operand: leaky_relu(xt)
-                        peak_m2[pass] = std::max(peak_m2[pass], xtm[q]);
+                        pt_wc[pass].push_back(xt[q]);                            // fp16 operand: leaky_relu(xt)
+                        pt_m2[pass].push_back(xtm[q]);
                         xtm[q] *= 0.505;
                     }
                     if (!conv(rb + ".convs2." + std::to_string(mth), xt, xtm, y, ym)) return false;
@@ -787,11 +790,18 @@ bool vocoder_fp16_analysis(dtts_ctx* h, Need& need) {
             m.swap(ms);
         }
     }
-    // bound(M) <= const + (at M = 1 minus const) * M: every channel bound is affine in M with non-negative coefficients
-    h->wc_const = peak_wc[0];
-    h->wc_lin = std::max(0.0, peak_wc[1] - peak_wc[0]);
-    h->est_const = std::sqrt(peak_m2[0]);
-    h->est_lin = std::sqrt(std::max(0.0, peak_m2[1] - peak_m2[0]));
+    if (pt_wc[0].size() != pt_wc[1].size()) return false;
+    double a_wc = 0, b_wc = 0, a_m2 = 0, b_m2 = 0;   // max_q a_q, max_q b_q (possibly different channels: that is the point)
+    for (size_t q = 0; q < pt_wc[0].size(); ++q) {
+        a_wc = std::max(a_wc, pt_wc[0][q]);
+        b_wc = std::max(b_wc, pt_wc[1][q] - pt_wc[0][q]);
+        a_m2 = std::max(a_m2, pt_m2[0][q]);
+        b_m2 = std::max(b_m2, pt_m2[1][q] - pt_m2[0][q]);
+    }
+    h->wc_const = a_wc;
+    h->wc_lin = b_wc;
+    h->est_const = std::sqrt(a_m2);
+    h->est_lin = std::sqrt(b_m2);
     return true;
 }
 
@@ -1398,9 +1408,18 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
                         vp.stats = dstats;
                     }
 #endif
+                    // round 6: the stream BETWEEN the three iterations is fp16 (DTTS_VOC_F16 only; tune bit 15: fp32 as in round 5).  fp16(x) is what the
+                    // next iteration's convolution operand was anyway; the residual add sees the rounded value (tools/precision_sim.py --stream:
+                    // waveform error 5.3e-5 -> 6.7e-5, gate 1e-4).  The ResBlock's RESULT (iteration 2) stays fp32.
+                    const bool s16 = exact && !DTTS_TUNE(h, 32768);
+                    // (ablation builds: DTTS_S16 = mask of the hops that are 16-bit — bit 2 i: iteration 0 -> 1 of stage i, bit 2 i + 1: iteration 1 -> 2)
+                    static const int s16m = ablate_env("DTTS_S16") ? atoi(ablate_env("DTTS_S16")) : ~0;
+                    const bool hop_a = s16 && ((s16m >> (2 * i)) & 1), hop_b = s16 && ((s16m >> (2 * i + 1)) & 1);
+                    vp.x16 = (mth == 1 ? hop_a : (mth == 2 ? hop_b : false)) ? 1 : 0;
                     if (mth < 2) {
                         vp.y = mth == 0 ? Rf : Rg;
                         vp.mode = 1;
+                        vp.y16 = (mth == 0 ? hop_a : hop_b) ? 1 : 0;
                     } else {
                         vp.y = Sf;
                         vp.mode = j == 0 ? 1 : (j == nk - 1 ? 3 : 2);

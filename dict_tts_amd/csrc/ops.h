@@ -27,7 +27,8 @@ hipError_t mha_launch(const float* qkv, float* out, const int* lens, int B, int 
 //   logits[key_map == 0] = -1e9 ; w = softmax_l ; wv = sum_l w[l] * values[l,:]   (context = Wo Wv wv, by the caller)
 //   s_i = sum_l w[l] [key_map == i] ; pron_w[p] = s_{pinyin_map[p]} ; forced rows one-hot (add_pron_rule)
 //   pron = sum_p pron_w[p] * pinyin_emb[pinyin[p]]
-// dict_attn is written transposed [B,1,L_k,T_w] as the reference returns it.
+// dict_attn is kept as [B][T_w][L_k] (a word's weights are one coalesced row); dtts_text2mel_fetch(DTTS_OUT_DICT_ATTN) transposes it into the
+// reference's [B,1,L_k,T_w] view on request.
 struct S2paArgs {
     const float* qk;       // [B*T_w][D]
     const float* keys;     // [B*T_w][L_k][D]
@@ -41,7 +42,7 @@ struct S2paArgs {
     const int* lens;              // [B] words per utterance, or null: the caller zeroes context for t >= lens[b]
                                   // (dict_encoder.py:140), so the value rows of those words are not streamed
     float* wv;                    // [B*T_w][D]
-    float* dict_attn;             // [B][1][L_k][T_w]
+    float* dict_attn;             // [B][T_w][L_k]  (NOT the reference's transposed view: see above)
     float* pron_attn;             // [B*T_w][P]
     float* pron;                  // [B*T_w][H]
     int B, T_w, L_k, P, D, H, n_pinyin, language_zh;

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
             // tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware exp2 / rcp, evaluated by every lane (libm's tanhf ran its ~45 instructions for
             // the one live lane in eight): absolute error <= 3e-7 (1 / 100 of an int16 step), saturates correctly at +-1.
             float pre[PR], th[PR];
-            bool nf = false;
+            int nf = 0;   // non-finite SAMPLES of this group (the same unit as vconv.hip's post_tanh detector: dtts_vocoder_nonfinite counts samples)
 #pragma unroll
             for (int i = 0; i < PR; ++i) {
                 pre[i] = a[i] + pb;
@@ -536,10 +536,10 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
                     const bool nonfin = !(__builtin_fabsf(pre[i]) <= 3.0e38f);
                     if (o < TTo && t < len) {
                         wb[t] = nonfin ? __builtin_nanf("") : th[i];
-                        nf |= nonfin;
+                        nf += nonfin ? 1 : 0;
                     }
                 }
-                if (nf && p.bad) atomicAdd(p.bad, 1u);   // (never on a healthy call)
+                if (nf && p.bad) atomicAdd(p.bad, (unsigned)nf);   // (never on a healthy call)
             }
         }
     }
@@ -582,6 +582,7 @@ static hipError_t rb_launch_cfg(const RBlockParams& p, hipStream_t stream) {
     constexpr int W = 32 * MT * WT, PITCH = C * 2 + 16, EP = C * 4 + 16;
     const int H = 6 * (p.K - 1), TT = W - 2 * H;
     if (TT < 32) return hipErrorInvalidValue;
+    if ((long long)p.T * C * 4 >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit byte offsets inside an utterance's buffer resource
     constexpr size_t ACT = (size_t)(W + 2 * RB_GUARD) * PITCH;
     size_t lds = TB ? std::max(2 * ACT, ACT + (size_t)RB_GUARD * PITCH + (size_t)WT * 32 * EP) : ACT + (size_t)WT * 32 * EP;   // TB: the staging rows lie over the xt buffer
     int TTo = TT;

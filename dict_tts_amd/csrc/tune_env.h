@@ -23,10 +23,11 @@ inline int cu_reserve() {
 
 // dtts_config.tune_flags (include/dicttts_hip.h).  The RELEASE library honours only the bits that have a parity / bit-identity test behind
 // them (tests/test_gpu_parity.py): 8 prior flow launch by launch on the exact-fp32 kernels, 9 all ResBlocks of a C <= 64 stage in one launch,
-// 12 the first two ResBlocks of the C = 32 stage in one launch, 13 two-product fp16 ups.1, 14 512-row tiles for every k at C = 64.  Every
+// 12 the first two ResBlocks of the C = 32 stage in one launch, 13 two-product fp16 ups.1, 14 512-row tiles for every k at C = 64, 15 the fp32
+// inter-iteration stream of the per-iteration ResBlock kernels (round 5's form; default since round 6: fp16).  Every
 // other bit is an untested tuning experiment: its code exists only in -DDTTS_ABLATE builds (`make ablate`), the branches fold away in the
 // release library, and dtts_create REJECTS such a bit there (DTTS_E_INVAL) instead of ignoring it.
-constexpr int TUNE_RELEASE_MASK = (1 << 8) | (1 << 9) | (1 << 12) | (1 << 13) | (1 << 14);
+constexpr int TUNE_RELEASE_MASK = (1 << 8) | (1 << 9) | (1 << 12) | (1 << 13) | (1 << 14) | (1 << 15);
 #ifdef DTTS_ABLATE
 constexpr int TUNE_MASK = ~0;
 #else

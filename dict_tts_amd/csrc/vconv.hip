@@ -460,6 +460,9 @@ static hipError_t vlaunch_x(const VConvParams& p, hipStream_t stream) {
     }
     if (p.C_out_pad % CO_T || p.C_in_pad % CK) return hipErrorInvalidValue;
     if (p.gate_H && (CO_T % 64)) return hipErrorInvalidValue;   // a tanh tile and its sigmoid partner must sit in one workgroup
+    // the split-operand staging addresses an utterance's fp32 rows through ONE buffer resource with 32-bit byte offsets (num_records =
+    // len * ldx * 4): an utterance beyond 2 GiB (> ~131 k mel frames in the last upsampler) would wrap silently — refused instead
+    if (X3 && p.xf && (long long)p.T * p.ldx * 4 >= (1LL << 31)) return hipErrorInvalidValue;
     dim3 grid((p.T + TT - 1) / TT, p.C_out_pad / CO_T, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dtts {
 
@@ -23,8 +24,17 @@ namespace dtts {
 // C = 256 (NT = 2 co-tiles per wave): the stage-1 ResBlocks; 128-row tiles only.
 // WT = 2 (C = 128): the four waves as 2 (time) x 2 (output channels), two co-tiles per wave — every activation fragment read from LDS feeds two
 // MFMAs instead of one (half the ds_read_b128 traffic; twice the weight fragments through the texture path, as at C = 256).
-template <int C, int TT, int EL, bool GUARD, int WT = 1>
+// X16 (round 6; EL_F16 only): the INPUT stream x is fp16 — iterations 1 and 2 of a ResBlock, whose predecessor stored its result with
+// p.y16.  fp16(x) is exactly what the fp32 stream's staging computed as the convolution operand, so c1's operands keep their bits; what
+// changes is the residual add (x16 + xt instead of x32 + xt).  The staging loads 8 channels per thread (half the bytes, half the
+// accesses), needs no conversion (leaky_relu on the packed pairs as they arrive) and writes 16 bytes per LDS access; the epilogue
+// re-reads 8 bytes per four channels and widens them in registers.
+// M1: a launch that can only be mode 1 (y = x', iterations 0 and 1): the epilogue carries no stage-sum registers and spends them on a deeper
+// prefetch of the residual rows instead (below).
+template <int C, int TT, int EL, bool GUARD, int WT = 1, bool X16 = false, bool M1 = false>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) void vpair_kernel(const VPairParams p) {
+    static_assert(!X16 || EL == EL_F16, "the 16-bit stream is fp16");
+    const int mode = M1 ? 1 : p.mode;
     constexpr bool PS = !(C == 128 && TT == 128 && WT == 1);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WC = 4 / WT, TW = TT / WT;     // waves over the output channels; rows of a time-wave
@@ -105,13 +115,54 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
     // t >= len exceeds num_records) returns zeros = the reference's zero padding, with no per-access compare; a thread
     // keeps its column and walks rows in steps of 8, so each access costs one v_add for its address.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const float* xu = p.x + brow * C;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, len * C * 4, 0x00020000);
+    constexpr int XB = X16 ? 2 : 4;                 // bytes per element of the input stream
+    const char* xu = (const char*)p.x + brow * C * XB;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, len * C * XB, 0x00020000);
     constexpr int RSTEP = 256 / F4;                 // rows between two accesses of a thread (8)
     const int c4 = tid % F4, r0 = tid / F4;
     const int a0 = t0 - h2 - h1;
     const int arows = TT + 2 * h1;
-    if (!DTTS_DBG(p, 4)) {
+    if constexpr (X16) {
+        if (!DTTS_DBG(p, 4)) {
+            constexpr int F8 = C / 8, RS8 = 256 / F8;   // 8 channels (16 bytes) per access; rows between two accesses of a thread (16 / 8)
+#ifndef VP_U16
+#define VP_U16 0
+#endif
+            // ALL loads of a thread in ONE batch (the tile's rows <= TT + 50: 19 / 23 accesses; the registers are free here, the accumulators
+            // are not live yet): one exposed HBM round trip per tile instead of two (round 6 stamps: staging 11.7 k cycles of a 90 k tile)
+            constexpr int U = VP_U16 ? VP_U16 : (TT + 50 + RS8 - 1) / RS8;
+            const int c8 = tid % F8, r8 = tid / F8;
+            const int nk = (arows + RS8 - 1) / RS8;
+            const int voff0 = ((a0 + r8) * C + c8 * 8) * 2;
+            char* lrow = smem + r8 * PITCH + c8 * 16;
+            const int rlim = p.tile_rows - r8;      // the last pass may reach past the tile's LDS rows (the tile table lives there)
+            const _Float16 hs = (_Float16)0.1f;
+            const f16x2_t slope2 = {hs, hs};
+            for (int kb = 0; kb < nk; kb += U) {
+                u32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)   // (an access past the tile's rows is sent out of range: zeros, no memory traffic)
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, kb + u < nk ? voff0 + (kb + u) * (RS8 * C * 2) : (int)0x80000000, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (kb + u >= nk || (kb + u) * RS8 >= rlim) continue;
+                    u32x4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w = v[u][e];   // (a scalar copy first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index)
+                        const f16x2_t hv = __builtin_bit_cast(f16x2_t, w);
+                        if constexpr (GUARD) {   // census: a stored value beyond the fp16 range arrives as +-inf (only the rows this tile outputs)
+                            const int rr = r8 + (kb + u) * RS8 - h1 - h2;
+                            if (rr >= 0 && rr < TTe)
+                                n_ovf += (__builtin_fabsf((float)hv[0]) > 65504.f ? 1 : 0) + (__builtin_fabsf((float)hv[1]) > 65504.f ? 1 : 0);
+                        }
+                        r[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hv, hv * slope2));
+                    }
+                    *(u32x4*)(lrow + (kb + u) * (RS8 * PITCH)) = r;
+                }
+            }
+        }
+    } else if (!DTTS_DBG(p, 4)) {
 #ifndef VP_U
 #define VP_U 12
 #endif
@@ -211,7 +262,9 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
     // slab are sent out of range explicitly.  The reads of slab m+1 are issued before slab m is processed.
     constexpr int PER = WT * 32 * F4 / 256;     // a pass moves one 32-row slab of every time-wave
     float* yu = p.y + brow * C;
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, len * C * 4, 0x00020000);
+    // (p.y16, mode 1 only: the result leaves as fp16 — the next iteration's X16 input; same rows, half the bytes)
+    const auto rs_y = p.y16 ? __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + brow * C * 2), 0, len * C * 2, 0x00020000)
+                            : __builtin_amdgcn_make_buffer_rsrc((void*)yu, 0, len * C * 4, 0x00020000);
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ya ? p.ya + brow * C : (unsigned short*)yu), 0, len * C * 2, 0x00020000);
     const int eoff0 = (t0 * C + c4 * 4) * 4;
     auto eoff = [&](int m, int u) {                 // byte offset of (slab m, access u) or out of range
@@ -219,21 +272,48 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
         const int o = (sr >> 5) * TW + m * 32 + (sr & 31);
         return o < TTe ? eoff0 + o * (C * 4) : (int)0x80000000;
     };
-    constexpr int EB = NT == 1 ? 2 : 1;   // slab reads double-buffered only while the registers allow it
-    u32x4 xin[EB][PER], sold[EB][PER];
-    auto fetch = [&](int m, u32x4 (&xi)[PER], u32x4 (&so)[PER]) {
+    // The residual rows (and, modes 2 / 3, the stage sum) of a slab are requested XD - 1 (SD - 1) slabs ahead.  Round 6 stamps: with one slab
+    // of lookahead the epilogue was a chain of exposed round trips — 34 k cycles of a 90 k-cycle tile at C = 128 for 8 slabs of ~1 k cycles of
+    // work each.  An fp16 stream costs half the registers per slab, so the same registers look twice as far ahead; a launch that can only be
+    // mode 1 (M1) has no stage-sum registers and spends them on the residual rows.  (Loads return in order: the effective lookahead of a
+    // mode 2 / 3 launch is that of its stage-sum ring.)
+#ifndef VP_XD
+#define VP_XD 0
+#endif
+#ifndef VP_SD
+#define VP_SD 0
+#endif
+#ifdef VP_EPI_R5   // (A/B builds) round 5's lookahead: one slab at C = 128, none at C = 256
+    constexpr int XD_DEF = NT == 1 ? 2 : 1;
+#else
+    constexpr int XD_DEF = NT == 1 ? (X16 ? (M1 ? 6 : 4) : (M1 ? 3 : 2)) : (X16 ? (M1 ? 3 : 2) : (M1 ? 2 : 1));
+#endif
+    constexpr int XD = (VP_XD ? VP_XD : XD_DEF) < MTT ? (VP_XD ? VP_XD : XD_DEF) : MTT;
+    constexpr int SD = M1 ? 1 : ((VP_SD ? VP_SD : (NT == 1 ? 2 : 1)) < MTT ? (VP_SD ? VP_SD : (NT == 1 ? 2 : 1)) : MTT);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    typedef typename std::conditional<X16, u32x2, u32x4>::type xrow_t;
+    xrow_t xin[XD][PER];
+    u32x4 sold[SD][PER];
+    auto fetch_x = [&](int m, xrow_t (&xi)[PER]) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, VP_XI_AUX);
-            if (p.mode >= 2) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, VP_LD_AUX);
+            if constexpr (X16) xi[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off == (int)0x80000000 ? off : off >> 1, 0, VP_XI_AUX);
+            else xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, VP_XI_AUX);
         }
     };
-    fetch(0, xin[0], sold[0]);
+    auto fetch_s = [&](int m, u32x4 (&so)[PER]) {
+        if (M1 || mode < 2) return;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, eoff(m, u), 0, VP_LD_AUX);
+    };
+#pragma unroll
+    for (int m = 0; m < XD - 1; ++m) fetch_x(m, xin[m]);
+#pragma unroll
+    for (int m = 0; m < SD - 1; ++m) fetch_s(m, sold[m]);
 #pragma unroll
     for (int m = 0; m < MTT; ++m) {
         if (m) __syncthreads();
-        if (EB == 1 && m) fetch(m, xin[0], sold[0]);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -243,21 +323,30 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
                 for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * q + e];
                 *(f32x4*)(smem + (wt * 32 + (lane & 31)) * EP + ((wc * NT + n) * 32 + 8 * q + 4 * (lane >> 5)) * 4) = v;
             }
-        if (EB == 2 && m + 1 < MTT) fetch(m + 1, xin[(m + 1) & 1], sold[(m + 1) & 1]);
+        if (m + XD - 1 < MTT) fetch_x(m + XD - 1, xin[(m + XD - 1) % XD]);
+        if (m + SD - 1 < MTT) fetch_s(m + SD - 1, sold[(m + SD - 1) % SD]);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + __builtin_bit_cast(f32x4, xin[m & (EB - 1)][u]);   // x = xt + x
-            if (p.mode >= 2) o += __builtin_bit_cast(f32x4, sold[m & (EB - 1)][u]);                                                 // xs += x
-            if (p.mode == 3) {
+            f32x4 xr;
+            if constexpr (X16) {
+                const unsigned w0 = xin[m % XD][u][0], w1 = xin[m % XD][u][1];   // (scalar copies: see the staging loop)
+                const f16x2_t g0 = __builtin_bit_cast(f16x2_t, w0), g1 = __builtin_bit_cast(f16x2_t, w1);
+                xr = f32x4{(float)g0[0], (float)g0[1], (float)g1[0], (float)g1[1]};
+            } else xr = __builtin_bit_cast(f32x4, xin[m % XD][u]);
+            f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + xr;   // x = xt + x
+            if (!M1 && mode >= 2) o += __builtin_bit_cast(f32x4, sold[m % SD][u]);                                                 // xs += x
+            if (!M1 && mode == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
-            if (!(p.mode == 3 && p.ya && p.drop_y))   // the stage's consumers read only the bf16 copy
+            if (p.y16) {   // (no saturation: a value beyond the fp16 range is stored as +-inf, reaches conv_post as a non-finite sum: the always-on detector)
+                const u32x2 pk = {pack2<EL_F16>(o[0], o[1]), pack2<EL_F16>(o[2], o[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_y, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
+            } else if (!(mode == 3 && p.ya && p.drop_y))   // the stage's consumers read only the bf16 copy
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, off, 0, VP_ST_AUX);
-            if (p.mode == 3 && p.ya) {
-                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            if (!M1 && mode == 3 && p.ya) {
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
                 __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
@@ -284,8 +373,16 @@ bool vpair_supported(int C, int K, int dil) {
     return (C == 128 || C == 256) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
 }
 
-template <int CC, int TT, int EL, bool GUARD = false, int WT = 1>
+template <int CC, int TT, int EL, bool GUARD = false, int WT = 1, bool X16 = false, bool M1 = false>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
+    if constexpr (EL == EL_F16 && !X16) {
+        if (p.x16) return vpair_launch_tt<CC, TT, EL, GUARD, WT, true, M1>(p, stream);
+    }
+    if constexpr (EL == EL_F16 && !M1) {   // the mode-1-only instantiations (iterations 0 / 1 of the 16-bit stream)
+        if (p.mode == 1 && p.y16) return vpair_launch_tt<CC, TT, EL, GUARD, WT, X16, true>(p, stream);
+    }
+    if ((p.x16 && !X16) || (p.y16 && (EL != EL_F16 || p.mode != 1))) return hipErrorInvalidValue;
+    if ((long long)p.T * CC * 4 >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit byte offsets inside an utterance's buffer resource
     constexpr int PITCH = CC * 2 + 16;
     const int h1 = p.dil * (p.K - 1) / 2, h2 = (p.K - 1) / 2;
     const int TTe = TT - 2 * h2;
@@ -298,14 +395,15 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     const size_t ep = (size_t)WT * 32 * (CC * 4 + 16);
     if (ep > lds) lds = ep;
     VPairParams q = p;
+    q.tile_rows = (int)rows;
     q.pre_off = (int)lds;                          // tile table: prefix sums [B + 1], counts [B], lengths [B]
     constexpr bool PS = !(CC == 128 && TT == 128 && WT == 1);
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if constexpr (EL == EL_F16 && !GUARD) {
-        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, WT>(p, stream);
+        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, WT, X16, M1>(p, stream);
     }
-    auto kern = vpair_kernel<CC, TT, EL, GUARD, WT>;
+    auto kern = vpair_kernel<CC, TT, EL, GUARD, WT, X16, M1>;
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;

@@ -100,7 +100,14 @@ class HifiGAN:
         self.fp16_status = None   # 'proven' | 'checked' | 'rejected' | None (not an fp16 mode)
         self.fp16_bound = None    # (worst_case, rms_estimate) at MEL_ABS_MAX
         if ctx is not None:
-            self.precision = precision
+            # a shared context computes in ITS OWN mode (dtts_config.vocoder_precision), whatever was asked for here: an explicit precision
+            # that disagrees is an error, AUTO takes the context's (it used to assume fp16 — a bf16 / bf16x3 context then claimed
+            # 'proven' and synchronised for the detector for nothing)
+            ctx_precision = int(ctx.cfg.vocoder_precision)
+            if not auto and precision != ctx_precision:
+                raise abi.DttsError(f"HifiGAN(ctx=..., precision={precision}): the shared context was created with vocoder_precision={ctx_precision}")
+            self.precision = ctx_precision
+            self._shared_ctx = True
             self.ctx = ctx
             self.ctx.load_state_dict("vocoder", state_dict)
             self.ctx.finalize(abi.PART_VOCODER)
@@ -180,8 +187,10 @@ class HifiGAN:
             torch.cuda.current_stream().synchronize()
             if self.overflowed():
                 if not (self._auto and self._state_dict is not None):
+                    how = ("create the shared context with vocoder_precision=DTTS_VOC_BF16X3 (a shared context cannot be rebuilt from here)"
+                           if getattr(self, "_shared_ctx", False) else "use precision='bf16x3' or leave the precision to AUTO")
                     raise abi.DttsError("DTTS_VOC_F16: an fp16 operand overflowed in this call (non-finite pre-tanh samples; the reference "
-                                        "computes in fp32, modules/hifigan/hifigan.py:51-58); use precision='bf16x3' or leave the precision to AUTO")
+                                        f"computes in fp32, modules/hifigan/hifigan.py:51-58); {how}")
                 import warnings
                 warnings.warn("HifiGAN: an fp16 operand overflowed in this call; switching to DTTS_VOC_BF16X3 and redoing it")
                 self._build(self._state_dict, abi.VOC_BF16X3, False)

@@ -114,6 +114,8 @@ typedef struct dtts_config {
                                            12 (schedule)   the first two ResBlocks of the C = 32 stage in one launch (neutral)
                                            13 (arithmetic) two-product fp16 ups.1 (eats waveform margin)
                                            14 (schedule)   512-row tiles for every k at C = 64
+                                           15 (arithmetic) fp32 stream between the three iterations of the C >= 128, k >= 7 ResBlocks (round 5's
+                                                           form; the default stores it as fp16: half the bytes, waveform error 5.3e-5 -> 6.7e-5)
                                          Builds made with -DDTTS_ABLATE (`make ablate`, tools/ab_tune.sh) additionally carry the untested
                                          experiments — 0 conv_post as its own kernel, 1 upsamplers without the zero-tap skip, 2 static tile
                                          assignment, 3 no whole-ResBlock fusion at C >= 128, 4 per-launch timer events, 5 128-row tiles for the

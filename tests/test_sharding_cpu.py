@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dict_tts_amd.shard import gather_mels, group_device, n_steps, ranks_seen, shard_indices
+from dict_tts_amd.shard import exchange_shapes, gather_mels, group_device, n_steps, ranks_seen, shard_indices
 
 
 def test_shard_indices_partition():
@@ -63,6 +63,25 @@ def _worker(rank, world, port, q):
             B, T = wm.shape[:2]
             ok = ok and torch.equal(mel_all[r, :B, :T], wm) and float(mel_all[r, B:].abs().sum()) == 0
             ok = ok and float(mel_all[r, :, T:].abs().sum()) == 0 and lens_all[r, :B].tolist() == wl.tolist()
+    # round 6: (a) the shape exchange started EARLY (right behind encode, where the host already knows B and T_mel) and read only inside
+    # gather_mels: same results, two exchanges of consecutive steps may be in flight at once; (b) the fixed-capacity gather, with no shape
+    # exchange at all (meta None; lens_all says which utterances exist); a batch beyond the capacity raises on the rank that holds it
+    early = [exchange_shapes(*(shapes[step][rank] or (0, 0)), dist) for step in (0, 1)]
+    for step in (0, 1):
+        mel, lens = mk(rank, step)
+        mel_all, lens_all, meta = gather_mels(mel, lens, dist, shapes=early[step])
+        mel_ref, lens_ref, meta_ref = gather_mels(mel, lens, dist)
+        ok = ok and torch.equal(mel_all, mel_ref) and torch.equal(lens_all, lens_ref) and torch.equal(meta, meta_ref)
+        mel_cap, lens_cap, meta_cap = gather_mels(mel, lens, dist, capacity=(4, 9))
+        ok = ok and meta_cap is None and tuple(mel_cap.shape) == (world, 4, 9, 80) and tuple(lens_cap.shape) == (world, 4)
+        Bm, Tm = mel_ref.shape[1:3]
+        ok = ok and torch.equal(mel_cap[:, :Bm, :Tm], mel_ref) and float(mel_cap[:, Bm:].abs().sum()) == 0 and float(mel_cap[:, :, Tm:].abs().sum()) == 0
+        ok = ok and torch.equal(lens_cap[:, :Bm], lens_ref) and int(lens_cap[:, Bm:].abs().sum()) == 0
+    try:
+        gather_mels(torch.zeros(5, 3, 80), torch.ones(5, dtype=torch.int32), dist, capacity=(4, 9))   # (raises BEFORE any collective: both ranks stay matched)
+        ok = False
+    except ValueError:
+        pass
     # the collectives' device follows the BACKEND (a rank without a batch must not fall back to a different device kind)
     ok = ok and group_device(dist) == torch.device("cpu")
     seen = ranks_seen(dist, device_index=10 + rank, device_uuid=f"GPU-fake-{rank}")

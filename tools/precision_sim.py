@@ -70,8 +70,9 @@ class Scheme:
         return y + b.view(1, -1, 1)
 
 
-def generator(sd, cfg, mel, scheme_of):
-    """scheme_of(layer_name) -> Scheme"""
+def generator(sd, cfg, mel, scheme_of, stream=None):
+    """scheme_of(layer_name) -> Scheme.  stream: None, or (set of (stage, kernel_size), set of iteration indices, kind): the residual
+    stream r LEAVING those iterations of those ResBlocks is stored in a 16-bit type (vpair's inter-iteration stream, round 6)."""
     L = href.LRELU_SLOPE
     x = scheme_of("conv_pre").conv(F.conv1d, mel, sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
     nk = len(cfg["resblock_kernel_sizes"])
@@ -91,6 +92,8 @@ def generator(sd, cfg, mel, scheme_of):
                 xt = F.leaky_relu(xt, L)
                 xt = sc.conv(F.conv1d, xt, sd[f"{p}.convs2.{m}.weight"], sd[f"{p}.convs2.{m}.bias"], padding=href._pad(rk, 1))
                 r = xt + r
+                if stream is not None and (i, rk) in stream[0] and m in stream[1]:
+                    r = rnd(r, stream[2])
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)
@@ -109,6 +112,11 @@ def main():
     ap.add_argument("--by-stage", default="")
     ap.add_argument("--mix", default="", help="layer=scheme,... with 'default=scheme'")
     ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--stream", default="", help="stage:kernel,... whose inter-iteration residual stream is stored 16-bit, e.g. 0:7,0:11,1:7,1:11 "
+                    "('all' = every ResBlock); evaluated on top of --stream-scheme")
+    ap.add_argument("--stream-iters", default="0,1", help="iterations whose OUTPUT is stored 16-bit (2 = also the ResBlock's result)")
+    ap.add_argument("--stream-kind", default="h", help="h = fp16, b = bf16")
+    ap.add_argument("--stream-scheme", default="h/h", help="arithmetic of the ResBlock stages under --stream (serial convolutions exact, as bf16x3 is)")
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     cfg = synth.hifigan_config()
@@ -132,6 +140,16 @@ def main():
                 for ln in layers:
                     w = generator(sd, cfg, mel, lambda n: sc if n == ln else exact).numpy().ravel()
                     print(f"  only {ln:10s} in {a.by_stage}: rms(d) {rms(w - ref):.3e}")
+            if a.stream:
+                nk = cfg["resblock_kernel_sizes"]
+                pairs = {(i, k) for i in range(4) for k in nk} if a.stream == "all" else {tuple(int(v) for v in t.split(":")) for t in a.stream.split(",")}
+                iters = {int(v) for v in a.stream_iters.split(",")}
+                sc = Scheme(a.stream_scheme)
+                pick = lambda n: sc if n.startswith("stage.") else exact
+                w0 = generator(sd, cfg, mel, pick).numpy().ravel()
+                w1 = generator(sd, cfg, mel, pick, stream=(pairs, iters, a.stream_kind)).numpy().ravel()
+                print(f"  stages {a.stream_scheme}, fp32 stream: rms(d) {rms(w0 - ref):.3e}   |  {a.stream_kind}16 stream after iterations {sorted(iters)} of {sorted(pairs)}: "
+                      f"rms(d) {rms(w1 - ref):.3e} |drms| {abs(rms(w1) - rms(ref)):.2e}")
             if a.mix:
                 m = dict(kv.split("=") for kv in a.mix.split(","))
                 scs = {k: Scheme(v) for k, v in m.items()}
