@@ -1145,6 +1145,20 @@ __global__ void scale_lens_kernel2(const int32_t* lens, int32_t* out, int B, int
     out[i] = l * mult.m[sidx];
 }
 
+// wav[b][i] = 0 for i >= lens[b] * hop: the samples past an utterance's end (the generator's last kernel writes the valid ones only).  Round 5
+// zero-filled the WHOLE [B][T * hop] buffer with hipMemsetAsync in front of every forward — 45 MB at B = 60, half of it about to be overwritten,
+// through rocclr's generic fill kernel (51 us on average beside the other stream's kernels, up to 395 us: profiles/r05_h_kernel_trace.md).
+__global__ void zero_wav_tails_kernel(float* wav, const int32_t* lens, int T, int hop) {
+    const int b = blockIdx.y;
+    const long long n = (long long)T * hop;
+    int l = lens[b];
+    l = l < 0 ? 0 : (l > T ? T : l);
+    const long long first = (long long)l * hop;                       // (hop is a multiple of 4: 16-byte stores stay aligned)
+    const long long i = first + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) *(float4*)(wav + (long long)b * n + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (long long k = i; k < n; ++k) wav[(long long)b * n + k] = 0.f;
+}
+
 // exact = DTTS_VOC_F16: fp32 tensors between kernels (no 16-bit copies), serial convolutions on split operands, ResBlock
 // kernels on fp16 operands
 int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, int B, int T, float* wav, hipStream_t s) {
@@ -1227,7 +1241,12 @@ int hifigan_forward_fused(dtts_ctx* h, const float* mel, const int32_t* lens, in
         for (int i = 0; i < nup; ++i) mult.m[i + 1] = mult.m[i] * c.upsample_rates[i];
         hipLaunchKernelGGL(scale_lens_kernel2, dim3((B * (nup + 1) + 255) / 256), dim3(256), 0, s, lens, lensS, B, T, nup + 1, mult);
     }
-    HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));  // samples past an utterance's end are zero
+    // samples past an utterance's end are zero (no lens: every sample is a valid one and is written below)
+    if (lens && (h->hop & 3) == 0 && ((uintptr_t)wav & 15) == 0) {
+        const long long n = (long long)T * h->hop;
+        hipLaunchKernelGGL(zero_wav_tails_kernel, dim3((unsigned)((n / 4 + 255) / 256), B), dim3(256), 0, s, wav, lens, T, h->hop);
+        HIPCHK(hipGetLastError());
+    } else if (lens) HIPCHK(hipMemsetAsync(wav, 0, (size_t)B * T * h->hop * sizeof(float), s));
     const int TV = DTTS_TIMER_VOC_CONV;
     // The family's launches are consecutive on the stream (nothing else runs between conv_pre and the last ResBlock / conv_post): ONE
     // hipEvent pair per forward spans them all — the per-launch pairs of round 2 put 50 event packets between the kernels of every forward

@@ -400,9 +400,19 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
     // row segments (8 NT lanes per row): no workgroup barrier inside the epilogue (round 3: 2 MT - 1 of them), the waves drift through their
     // slabs and HBM round trips independently.  (The LDS serves one wave's accesses in order.)
     constexpr int CW = NT * 32, F4W = CW / 4, RPI = 64 / F4W, NRD = 32 / RPI;
-    const int er = lane / F4W, ec = lane % F4W;                          // row within an access, 16-byte chunk of the wave's row segment
+    const int er = lane / F4W, ec = lane % F4W;                          // lane octet (one row per octet and access), 16-byte chunk of the wave's row segment
     const int goffw = (p.s_private ? (j * TT - H) * C : base_t * C) * 4 + (wc * CW + ec * 4) * 4;
-    auto erow = [&](int m, int u) { return (wt * MT + m) * 32 + u * RPI + er; };   // local tile row of (slab m, access u)
+    // Which of the slab's 32 rows an octet reads in access u.  Consecutive rows (u * 8 + er: rounds 3 - 5) put the 16-lane groups of a ds_read_b128
+    // ({0-3, 12-15, 20-27}, ...) on overlapping 16-byte slots of the 256-byte bank row — 3-way at C >= 64, 2-way at C = 32: 12 / 8 LDS cycles per read instead
+    // of 4, a quarter of the kernels' bank-conflict cycles (round 6: tools/lds_conflict_attrib.sh; the model reproduces the counter to 1 %).  Rows
+    // base + {0, 16, 8, 24} for the four octets of a half-wave (base = 2 u + half) spread every group over all 16 slots for each row pitch in use (9 / 17 / 33 / 65
+    // slots): conflict-free; an octet still moves one whole 128-byte row segment, so the global accesses coalesce as before.  Same values, same order per row.
+    static_assert(F4W == 8 && RPI == 8 && NRD == 4, "the conflict-free row order below is for 8 lanes per row, 8 rows per access");
+    // (C = 32 keeps consecutive rows: a row is 128 bytes there, so an access of 8 consecutive rows is ONE contiguous kilobyte of the stage sum — worth more than
+    // the 4 LDS cycles: +1.1 % on both C = 32 launches with the permuted order, same box)
+    const int erow_slab_base = C == 32 ? er : (er >> 2) + ((er & 1) ? 16 : 0) + ((er & 2) ? 8 : 0);
+    auto srow = [&](int u) { return (C == 32 ? 8 : 2) * u + erow_slab_base; };                // row of the 32-row slab
+    auto erow = [&](int m, int u) { return (wt * MT + m) * 32 + srow(u); };                   // local tile row of (slab m, access u)
     auto eoff = [&](int m, int u) {
         const int row = erow(m, u);
         return (row >= H && row < H + TT) ? goffw + row * (C * 4) : (int)0x80000000;
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(64 * WT * WC, (64 * WT * WC <= 256) ? 2 : 1) void r
 #pragma unroll
         for (int u = 0; u < NRD; ++u) {
             const int off = eoff(m, u);
-            f32x4 o = *(const f32x4*)(stg + (u * RPI + er) * EP + ec * 16);
+            f32x4 o = *(const f32x4*)(stg + srow(u) * EP + ec * 16);
             o += __builtin_bit_cast(f32x4, sold[m][u]);                // xs += resblock(x)  (hifigan.py:133-135); zeros in mode 0
             if (wav_now) {
                 const int row = erow(m, u);                            // local tile row

@@ -29,12 +29,10 @@ namespace dtts {
 // changes is the residual add (x16 + xt instead of x32 + xt).  The staging loads 8 channels per thread (half the bytes, half the
 // accesses), needs no conversion (leaky_relu on the packed pairs as they arrive) and writes 16 bytes per LDS access; the epilogue
 // re-reads 8 bytes per four channels and widens them in registers.
-// M1: a launch that can only be mode 1 (y = x', iterations 0 and 1): the epilogue carries no stage-sum registers and spends them on a deeper
-// prefetch of the residual rows instead (below).
-template <int C, int TT, int EL, bool GUARD, int WT = 1, bool X16 = false, bool M1 = false>
+template <int C, int TT, int EL, bool GUARD, int WT = 1, bool X16 = false>
 __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) void vpair_kernel(const VPairParams p) {
     static_assert(!X16 || EL == EL_F16, "the 16-bit stream is fp16");
-    const int mode = M1 ? 1 : p.mode;
+    const int mode = p.mode;
     constexpr bool PS = !(C == 128 && TT == 128 && WT == 1);   // persistent workgroups (below); not the 3-per-CU configuration, which loses 9 % with them
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WC = 4 / WT, TW = TT / WT;     // waves over the output channels; rows of a time-wave
@@ -126,11 +124,11 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
         if (!DTTS_DBG(p, 4)) {
             constexpr int F8 = C / 8, RS8 = 256 / F8;   // 8 channels (16 bytes) per access; rows between two accesses of a thread (16 / 8)
 #ifndef VP_U16
-#define VP_U16 0
+#define VP_U16 (RS8 == 16 ? 10 : 12)
 #endif
-            // ALL loads of a thread in ONE batch (the tile's rows <= TT + 50: 19 / 23 accesses; the registers are free here, the accumulators
-            // are not live yet): one exposed HBM round trip per tile instead of two (round 6 stamps: staging 11.7 k cycles of a 90 k tile)
-            constexpr int U = VP_U16 ? VP_U16 : (TT + 50 + RS8 - 1) / RS8;
+            // independent loads in flight per thread and batch.  (All 19 / 23 accesses of a tile in ONE batch — one exposed round trip instead of
+            // two — shortens wave 0's staging phase and not the launch: LABNOTES round 6 (b).)
+            constexpr int U = VP_U16;
             const int c8 = tid % F8, r8 = tid / F8;
             const int nk = (arows + RS8 - 1) / RS8;
             const int voff0 = ((a0 + r8) * C + c8 * 8) * 2;
@@ -272,24 +270,17 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
         const int o = (sr >> 5) * TW + m * 32 + (sr & 31);
         return o < TTe ? eoff0 + o * (C * 4) : (int)0x80000000;
     };
-    // The residual rows (and, modes 2 / 3, the stage sum) of a slab are requested XD - 1 (SD - 1) slabs ahead.  Round 6 stamps: with one slab
-    // of lookahead the epilogue was a chain of exposed round trips — 34 k cycles of a 90 k-cycle tile at C = 128 for 8 slabs of ~1 k cycles of
-    // work each.  An fp16 stream costs half the registers per slab, so the same registers look twice as far ahead; a launch that can only be
-    // mode 1 (M1) has no stage-sum registers and spends them on the residual rows.  (Loads return in order: the effective lookahead of a
-    // mode 2 / 3 launch is that of its stage-sum ring.)
+    // The residual rows (and, modes 2 / 3, the stage sum) of a slab are requested XD - 1 (SD - 1) slabs ahead: one slab at C = 128, none at
+    // C = 256 (registers).  Round 6 stamps had this epilogue at 34 k cycles of a 90 k-cycle tile at C = 128 — a chain of exposed round trips; a
+    // lookahead of 3 - 5 slabs (-DVP_XD / -DVP_SD; an fp16 row costs half the registers) shortens wave 0's phase by 27 - 40 % and leaves every
+    // launch where it was (the co-resident workgroup fills the gaps either way): the shallow ring stays.  LABNOTES round 6 (b).
 #ifndef VP_XD
-#define VP_XD 0
+#define VP_XD (NT == 1 ? 2 : 1)
 #endif
 #ifndef VP_SD
-#define VP_SD 0
+#define VP_SD (NT == 1 ? 2 : 1)
 #endif
-#ifdef VP_EPI_R5   // (A/B builds) round 5's lookahead: one slab at C = 128, none at C = 256
-    constexpr int XD_DEF = NT == 1 ? 2 : 1;
-#else
-    constexpr int XD_DEF = NT == 1 ? (X16 ? (M1 ? 6 : 4) : (M1 ? 3 : 2)) : (X16 ? (M1 ? 3 : 2) : (M1 ? 2 : 1));
-#endif
-    constexpr int XD = (VP_XD ? VP_XD : XD_DEF) < MTT ? (VP_XD ? VP_XD : XD_DEF) : MTT;
-    constexpr int SD = M1 ? 1 : ((VP_SD ? VP_SD : (NT == 1 ? 2 : 1)) < MTT ? (VP_SD ? VP_SD : (NT == 1 ? 2 : 1)) : MTT);
+    constexpr int XD = VP_XD < MTT ? VP_XD : MTT, SD = VP_SD < MTT ? VP_SD : MTT;
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     typedef typename std::conditional<X16, u32x2, u32x4>::type xrow_t;
     xrow_t xin[XD][PER];
@@ -303,7 +294,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
         }
     };
     auto fetch_s = [&](int m, u32x4 (&so)[PER]) {
-        if (M1 || mode < 2) return;
+        if (mode < 2) return;
 #pragma unroll
         for (int u = 0; u < PER; ++u) so[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, eoff(m, u), 0, VP_LD_AUX);
     };
@@ -336,8 +327,8 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
                 xr = f32x4{(float)g0[0], (float)g0[1], (float)g1[0], (float)g1[1]};
             } else xr = __builtin_bit_cast(f32x4, xin[m % XD][u]);
             f32x4 o = *(const f32x4*)(smem + (r0 + u * RSTEP) * EP + c4 * 16) + xr;   // x = xt + x
-            if (!M1 && mode >= 2) o += __builtin_bit_cast(f32x4, sold[m % SD][u]);                                                 // xs += x
-            if (!M1 && mode == 3) {
+            if (mode >= 2) o += __builtin_bit_cast(f32x4, sold[m % SD][u]);                                                 // xs += x
+            if (mode == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] / p.div;
             }
@@ -346,7 +337,7 @@ __global__ __launch_bounds__(256, (C == 128 && TT == 128 && WT == 1) ? 3 : 2) vo
                 __builtin_amdgcn_raw_buffer_store_b64(pk, rs_y, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             } else if (!(mode == 3 && p.ya && p.drop_y))   // the stage's consumers read only the bf16 copy
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, off, 0, VP_ST_AUX);
-            if (!M1 && mode == 3 && p.ya) {
+            if (mode == 3 && p.ya) {
                 const u32x2 pk = {pack2bf(lrelu(o[0], p.slope), lrelu(o[1], p.slope)), pack2bf(lrelu(o[2], p.slope), lrelu(o[3], p.slope))};
                 __builtin_amdgcn_raw_buffer_store_b64(pk, rs_a, off == (int)0x80000000 ? off : off >> 1, 0, VP_ST_AUX);
             }
@@ -373,13 +364,10 @@ bool vpair_supported(int C, int K, int dil) {
     return (C == 128 || C == 256) && (K & 1) && K >= 3 && K <= 11 && dil >= 1 && dil <= 5;
 }
 
-template <int CC, int TT, int EL, bool GUARD = false, int WT = 1, bool X16 = false, bool M1 = false>
+template <int CC, int TT, int EL, bool GUARD = false, int WT = 1, bool X16 = false>
 static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     if constexpr (EL == EL_F16 && !X16) {
-        if (p.x16) return vpair_launch_tt<CC, TT, EL, GUARD, WT, true, M1>(p, stream);
-    }
-    if constexpr (EL == EL_F16 && !M1) {   // the mode-1-only instantiations (iterations 0 / 1 of the 16-bit stream)
-        if (p.mode == 1 && p.y16) return vpair_launch_tt<CC, TT, EL, GUARD, WT, X16, true>(p, stream);
+        if (p.x16) return vpair_launch_tt<CC, TT, EL, GUARD, WT, true>(p, stream);
     }
     if ((p.x16 && !X16) || (p.y16 && (EL != EL_F16 || p.mode != 1))) return hipErrorInvalidValue;
     if ((long long)p.T * CC * 4 >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit byte offsets inside an utterance's buffer resource
@@ -401,9 +389,9 @@ static hipError_t vpair_launch_tt(const VPairParams& p, hipStream_t stream) {
     if (PS) lds += (size_t)(3 * p.B + 2) * sizeof(int);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if constexpr (EL == EL_F16 && !GUARD) {
-        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, WT, X16, M1>(p, stream);
+        if (p.ovf) return vpair_launch_tt<CC, TT, EL, true, WT, X16>(p, stream);
     }
-    auto kern = vpair_kernel<CC, TT, EL, GUARD, WT, X16, M1>;
+    auto kern = vpair_kernel<CC, TT, EL, GUARD, WT, X16>;
     // per device (hipFuncSetAttribute is per device; a process may hold contexts on several GPUs)
     static bool configured_dev[64] = {};
     int cur_dev = 0;
