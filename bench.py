@@ -746,7 +746,9 @@ def main():
         if iso is not None and iso[0] > 0:
             ia = FLOP_PER_FRAME_VOCODER * iso[2] / (iso[0] * 1e-3) / 1e12
             out["roofline"]["isolated"] = {"achieved": ia, "frac": ia / PEAK_BF16_TFLOPS, "frac_of_data_ceiling": ia / DATA_CEILING_F16_TFLOPS,
-                                           "kernel_ms_per_forward": iso[0], "launches": iso[1]}
+                                           "kernel_ms_per_forward": iso[0], "launches": iso[1], "mel_frames": iso[2],
+                                           "what": "three forwards of the LAST timed batch alone on the GPU; achieved / frac are priced on THAT batch's own valid "
+                                                   "frame count (mel_frames), not on the run's average batch"}
         if side:
             out["side"] = side
         if modes:
