@@ -517,25 +517,36 @@ def main():
         voc.ctx.timer_reset()
         hb = next(b for b in batches if b is not None)
         d = {k: hb[k].to(dev) for k in ("word_tokens", "entry_ids", "pron_modified")}
-        ms_enc = ms_dec = ms_voc = 0.0
         stream = torch.cuda.current_stream().cuda_stream
-        for _ in range(3):
+        # one untimed pass (it also sizes the caller-owned mel / length buffers, which the timed passes reuse: the same batch every time, so
+        # no allocator call sits between the events), then the MEDIAN of five — round 5 averaged three passes including the first one, and an
+        # allocator round trip inside the decode bracket showed up as +0.4 ms on one box
+        reps_e, reps_d, reps_v = [], [], []
+        mel_i = lens_i = None
+        for rep in range(6):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
             T_m = m.ctx.text2mel_encode_ids(ptr(d["word_tokens"]), ptr(d["entry_ids"]), ptr(d["pron_modified"]), None,
                                             hb["B"], hb["T_w"], hb["L_k"], hb["P"], stream)
             ev[1].record()
-            mel_i = torch.empty(hb["B"], T_m, 80, device=dev)
+            if mel_i is None or mel_i.shape[1] != T_m:
+                mel_i = torch.empty(hb["B"], T_m, 80, device=dev)
+                lens_i = torch.empty(hb["B"], dtype=torch.int32, device=dev)
             m.ctx.text2mel_decode(None, mel_i.data_ptr(), stream)
-            lens_i = torch.empty(hb["B"], dtype=torch.int32, device=dev)
             m.ctx.fetch(abi.OUT_MEL_LENS, lens_i.data_ptr(), stream)
             ev[2].record()
             voc.forward_batch(mel_i, lens_i)
             ev[3].record()
             torch.cuda.synchronize()
-            ms_enc += ev[0].elapsed_time(ev[1]) / 3
-            ms_dec += ev[1].elapsed_time(ev[2]) / 3
-            ms_voc += ev[2].elapsed_time(ev[3]) / 3
+            if rep == 0:
+                m.ctx.timer_reset()
+                voc.ctx.timer_reset()
+                continue
+            reps_e.append(ev[0].elapsed_time(ev[1]))
+            reps_d.append(ev[1].elapsed_time(ev[2]))
+            reps_v.append(ev[2].elapsed_time(ev[3]))
+        med = lambda v: sorted(v)[len(v) // 2]
+        ms_enc, ms_dec, ms_voc = med(reps_e), med(reps_d), med(reps_v)
         s2pa_ms, s2pa_n = m.ctx.timer_read(abi.TIMER_S2PA)
         per_call = lambda ctx, which: (lambda ms, n: ms / max(n, 1))(*ctx.timer_read(which))
         ref_names = {"encoder": per_call(m.ctx, abi.TIMER_STAGE_ENCODER), "dict_encoder": per_call(m.ctx, abi.TIMER_STAGE_DICT_ENCODER),
@@ -544,6 +555,7 @@ def main():
         dec_tf = FLOP_PER_FRAME_DECODER * hb["B"] * T_m / (ms_dec * 1e-3) / 1e12
         stages = {"isolated": True, "batch": "first batch of this rank", "mel_frames_per_batch": fr,
                   "reference_profile_infer_timers_ms": ref_names,   # utils.Timer names of modules/dict_tts/model.py:50,57,86, vocoders/hifigan.py:59
+                  "how": "one untimed pass, then the median of five passes of encode | decode | vocoder between torch events on one stream",
                   "text2mel": {"ms": ms_enc + ms_dec, "encode_ms": ms_enc, "decode_ms": ms_dec,
                                "mel_frames_per_s": fr / ((ms_enc + ms_dec) * 1e-3)},
                   "vocoder": {"ms": ms_voc, "mel_frames_per_s": fr / (ms_voc * 1e-3)},

@@ -1,3 +1,6 @@
+"""Which hop of the 16-bit inter-iteration stream changes the waveform, and by how much?  Compares DTTS_VOC_F16 with the fp16 stream (tune 0) against the fp32
+stream (tune_flags bit 15) on the same mels; with the ablation library (LIB=dict_tts_amd/libdicttts_abl.so) DTTS_S16 masks single hops (bit 2 i: iteration 0 -> 1 of
+stage i, bit 2 i + 1: iteration 1 -> 2).  usage: [LIB=...] [DTTS_S16=mask] [B=2 T=48] python tools/stream16_bisect.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
