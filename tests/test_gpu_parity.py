@@ -1009,6 +1009,37 @@ def test_two_product_upsampler_option_stays_inside_the_gate(voc_sd, oracle_voc_s
     assert not np.array_equal(base, opt) and rms(base - want) < rms(opt - want)
 
 
+def test_fp16_inter_iteration_stream_vs_fp32_stream(voc_sd, oracle_voc_sd):
+    """Round 6: the residual stream between the three iterations of the per-iteration ResBlock kernels (C >= 128, k >= 7) is fp16 by
+    default; dtts_config.tune_flags bit 15 restores round 5's fp32 stream.  fp16(x) is the value the next iteration's MFMA operand was rounded to
+    anyway, so the two modes differ only through the residual add: both inside the waveform gate in the census fixture (0 clamped), the fp32 stream
+    the more exact one, the fp16 stream below the adoption bound the verdict set (8e-5), the two results different (the option really ran) — and an
+    overflow is seen by the always-on detector in BOTH modes (the stored stream does not saturate: +-inf reaches conv_post)."""
+    from dict_tts_amd import vocoder
+    from oracle import hifigan_ref as href
+    cfg = synth.hifigan_config()
+    mels = [synth.random_mel(31 + i, 72 + 24 * i, f"s16_{i}") for i in range(3)]
+    want = [href.spec2wav(oracle_voc_sd, cfg, m).numpy() for m in mels]
+    v16 = vocoder.HifiGAN(state_dict=voc_sd, config=cfg, precision="f16", range_guard=True)
+    v32 = vocoder.HifiGAN(state_dict=voc_sd, config={**cfg, "dtts_tune_flags": 1 << 15}, precision="f16", range_guard=True)
+    w16, w32 = v16.spec2wav_batch(mels), v32.spec2wav_batch(mels)
+    e16 = e32 = 0.0
+    for a16, a32, ref in zip(w16, w32, want):
+        wave_gate(a16, ref)
+        wave_gate(a32, ref)
+        assert not np.array_equal(a16, a32)
+        e16, e32 = max(e16, rms(a16 - ref)), max(e32, rms(a32 - ref))
+    print(f"\n[fp16 stream] waveform RMS error: fp32 stream {e32:.3e}, fp16 stream {e16:.3e} (gate 1e-4)")
+    assert e32 < e16 <= 8e-5, (e32, e16)
+    # one utterance alone == the same utterance inside the ragged batch, in the fp16-stream mode too (rows of other utterances never mix in)
+    assert np.array_equal(v16.spec2wav(mels[1]), w16[1])
+    hot = mels[0] * 3e6
+    for tune in (0, 1 << 15):
+        v = vocoder.HifiGAN(state_dict=voc_sd, config={**cfg, "dtts_tune_flags": tune}, precision="f16")
+        with pytest.raises(abi.DttsError, match="overflowed"):
+            v.spec2wav(hot)
+
+
 def test_fp16_validity_is_decided_statically_and_checked_on_every_call(voc_sd, oracle_voc_sd):
     """fp16 ResBlock operands overflow where the reference computes in fp32 (hifigan.py:51-58).  Whether DTTS_VOC_F16 is valid
     is a DECISION: a static bound from the folded weights (dtts_vocoder_fp16_bound) + the conv_post epilogue's always-on detector
