@@ -1339,7 +1339,7 @@ def test_mel_allgather_is_off_the_critical_path_two_ranks_one_device():
     """the step with the mel all-gather and with --no-gather.  The shape exchange no longer blocks the host in front of the
     vocoder's launches (dict_tts_amd/shard.py:exchange_shapes; bench.py starts it right behind encode and reads it after the batch has been
     enqueued).  Under the one-device hook both ranks share cuda:0 and the gather itself runs through gloo on the HOST (a D2H of the mel, a
-    CPU all-gather) — far more work than RCCL on device buffers — so the bound here is loose (10 %; measured and printed); what the test
+    CPU all-gather) — far more work than RCCL on device buffers — so the bound here is 5 % (measured x0.98 - x0.99 on three runs: the gathered step is not slower at all; printed); what the test
     pins is that the gathered step is not the SERIAL sum it was when the host waited for the decoder before launching the vocoder."""
     import json
     import socket
@@ -1365,7 +1365,7 @@ def test_mel_allgather_is_off_the_critical_path_two_ranks_one_device():
     ratio = on["ms_per_step"] / off["ms_per_step"]
     print(f"\n[gather off the critical path] 2 ranks on one device: {off['ms_per_step']:.2f} ms/step without the gather, {on['ms_per_step']:.2f} with it "
           f"(x{ratio:.3f})")
-    assert ratio < 1.10, (off["ms_per_step"], on["ms_per_step"])
+    assert ratio < 1.05, (off["ms_per_step"], on["ms_per_step"])
 
 
 def test_config5_b128_single_gpu_superset_vs_oracle(acoustic, oracle_sd):
